@@ -1,0 +1,295 @@
+"""ctypes/numpy front-end of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product path (llm-inference-engine_amd/) never does.
+Every function takes/returns numpy arrays (float32 / int32) and forwards to
+oracle/libllmie_oracle.so, whose C source cites the reference file:line each
+algorithm follows (oracle/llmie_oracle.h).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libllmie_oracle.so")
+
+
+def build(force=False):
+    """Compile oracle/llmie_oracle.c with gcc (make -C oracle)."""
+    src = os.path.join(_HERE, "llmie_oracle.c")
+    hdr = os.path.join(_HERE, "llmie_oracle.h")
+    stale = (not os.path.exists(_LIB_PATH)
+             or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libllmie_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_uniform_philox.restype = C.c_float
+        _lib.orc_uniform_philox.argtypes = [C.c_uint32, C.c_uint32]
+        _lib.orc_num_threads.restype = C.c_int
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def input_embedding(ids, table):
+    ids, table = _i(ids), _f(table)
+    out = np.empty((ids.size, table.shape[1]), np.float32)
+    lib().orc_input_embedding(_p(ids), _p(table), _p(out), C.c_int(ids.size), C.c_int(table.shape[1]))
+    return out
+
+
+def cal_padding_offset(lens, max_q_len, fill=-1):
+    lens = _i(lens)
+    bs = lens.size
+    off = np.full((bs, max_q_len), fill, np.int32)
+    cum = np.empty(bs + 1, np.int32)
+    lib().orc_cal_padding_offset(_p(off), _p(cum), _p(lens), C.c_int(bs), C.c_int(max_q_len))
+    return off, cum
+
+
+def build_causal_mask(q_lens, k_lens, max_q_len, max_k_len):
+    q_lens, k_lens = _i(q_lens), _i(k_lens)
+    mask = np.empty((q_lens.size, max_q_len, max_k_len), np.float32)
+    lib().orc_build_causal_mask(_p(mask), _p(q_lens), _p(k_lens), C.c_int(q_lens.size),
+                                C.c_int(max_q_len), C.c_int(max_k_len))
+    return mask
+
+
+def rmsnorm(x, gamma, eps):
+    """returns (normed, residual)"""
+    x = _f(x).copy()
+    resid = np.empty_like(x)
+    gamma = _f(gamma)
+    lib().orc_rmsnorm(_p(x), _p(resid), _p(gamma), C.c_float(eps), C.c_int(x.shape[0]), C.c_int(x.shape[1]))
+    return x, resid
+
+
+def fused_add_bias_residual_rmsnorm(resid, out, bias, gamma, eps):
+    """returns (normed_out, new_residual)"""
+    resid, out = _f(resid).copy(), _f(out).copy()
+    bias = None if bias is None else _f(bias)
+    gamma = _f(gamma)
+    lib().orc_fused_add_bias_residual_rmsnorm(_p(resid), _p(out), _p(bias), _p(gamma), C.c_float(eps),
+                                              C.c_int(out.shape[0]), C.c_int(out.shape[1]))
+    return out, resid
+
+
+def add_residual(resid, out):
+    resid, out = _f(resid), _f(out).copy()
+    lib().orc_add_residual(_p(resid), _p(out), C.c_int(out.shape[0]), C.c_int(out.shape[1]))
+    return out
+
+
+def linear(x, w, trans_b=True):
+    x, w = _f(x), _f(w)
+    M, K = x.shape
+    N = w.shape[0] if trans_b else w.shape[1]
+    assert (w.shape[1] if trans_b else w.shape[0]) == K
+    y = np.empty((M, N), np.float32)
+    lib().orc_linear(_p(x), _p(w), _p(y), C.c_int(M), C.c_int(K), C.c_int(N), C.c_int(int(trans_b)))
+    return y
+
+
+def batched_gemm(a, b, trans_b):
+    a, b = _f(a), _f(b)
+    bs, nh, m, k = a.shape
+    n = b.shape[2] if trans_b else b.shape[3]
+    c = np.empty((bs, nh, m, n), np.float32)
+    lib().orc_batched_gemm(_p(a), _p(b), _p(c), C.c_int(bs * nh), C.c_int(m), C.c_int(n), C.c_int(k),
+                           C.c_int(int(trans_b)))
+    return c
+
+
+def qkv_bias_transpose_rope(qkv, bias, padding_offset, history_len, batch, seq_len,
+                            head_num, kv_head_num, head_size, rotary_dim, rotary_base, fill=0.0):
+    qkv = _f(qkv)
+    T = qkv.shape[0]
+    q = np.full((batch, head_num, seq_len, head_size), fill, np.float32)
+    k = np.full((batch, kv_head_num, seq_len, head_size), fill, np.float32)
+    v = np.full((batch, kv_head_num, seq_len, head_size), fill, np.float32)
+    bias = None if bias is None else _f(bias)
+    po, hl = _i(padding_offset).reshape(-1), _i(history_len)
+    lib().orc_qkv_bias_transpose_rope(_p(q), _p(k), _p(v), _p(qkv), _p(bias), _p(po), _p(hl),
+                                      C.c_int(batch), C.c_int(seq_len), C.c_int(T), C.c_int(head_num),
+                                      C.c_int(kv_head_num), C.c_int(head_size), C.c_int(rotary_dim),
+                                      C.c_float(rotary_base))
+    return q, k, v
+
+
+def rope_decode(qkv, head_num, kv_head_num, head_size, step, rotary_dim, rotary_base):
+    qkv = _f(qkv).copy()
+    lib().orc_rope_decode(_p(qkv), C.c_int(qkv.shape[0]), C.c_int(head_num), C.c_int(kv_head_num),
+                          C.c_int(head_size), C.c_int(step), C.c_int(rotary_dim), C.c_float(rotary_base))
+    return qkv
+
+
+def decoder_mha(qkv, qkv_bias, k_cache, v_cache, layer, head_num, kv_head_num, head_size, step):
+    """k_cache/v_cache [L,bs,kvh,max_seq,hs] are updated IN PLACE (float32 arrays); returns out [bs, nh*hs]"""
+    qkv = _f(qkv)
+    assert k_cache.dtype == np.float32 and k_cache.flags.c_contiguous
+    assert v_cache.dtype == np.float32 and v_cache.flags.c_contiguous
+    bs = qkv.shape[0]
+    max_seq = k_cache.shape[3]
+    out = np.empty((bs, head_num * head_size), np.float32)
+    bias = None if qkv_bias is None else _f(qkv_bias)
+    lib().orc_decoder_mha(_p(qkv), _p(bias), _p(k_cache), _p(v_cache), _p(out), C.c_int(layer), C.c_int(bs),
+                          C.c_int(head_num), C.c_int(kv_head_num), C.c_int(head_size), C.c_int(max_seq),
+                          C.c_int(step))
+    return out
+
+
+def concat_kv(src, cache, cur_len, history_len, layer):
+    """cache [L,bs,kvh,max_seq,hs] updated IN PLACE"""
+    src = _f(src)
+    assert cache.dtype == np.float32 and cache.flags.c_contiguous
+    bs, kvh, max_q, hs = src.shape
+    lib().orc_concat_kv(_p(src), _p(cache), _p(_i(cur_len)), _p(_i(history_len)), C.c_int(layer), C.c_int(bs),
+                        C.c_int(kvh), C.c_int(max_q), C.c_int(cache.shape[3]), C.c_int(hs))
+    return cache
+
+
+def repeat_kv(cache, ctx_len, layer, head_num, max_k_len, fill=0.0):
+    cache = _f(cache)
+    _, bs, kvh, max_seq, hs = cache.shape
+    dst = np.full((bs, head_num, max_k_len, hs), fill, np.float32)
+    lib().orc_repeat_kv(_p(cache), _p(dst), _p(_i(ctx_len)), C.c_int(layer), C.c_int(bs), C.c_int(head_num),
+                        C.c_int(kvh), C.c_int(max_k_len), C.c_int(max_seq), C.c_int(hs))
+    return dst
+
+
+def scale_mask_softmax(qk, mask, scale):
+    qk, mask = _f(qk), _f(mask)
+    bs, nh, ql, kl = qk.shape
+    out = np.empty_like(qk)
+    lib().orc_scale_mask_softmax(_p(qk), _p(mask), _p(out), C.c_float(scale), C.c_int(bs), C.c_int(nh),
+                                 C.c_int(ql), C.c_int(kl))
+    return out
+
+
+def transpose_remove_padding(src, padding_offset, num_tokens):
+    src = _f(src)
+    bs, nh, S, hs = src.shape
+    dst = np.empty((num_tokens, nh, hs), np.float32)
+    po = _i(padding_offset).reshape(-1)
+    lib().orc_transpose_remove_padding(_p(src), _p(dst), _p(po), C.c_int(num_tokens), C.c_int(bs), C.c_int(S),
+                                       C.c_int(nh), C.c_int(hs))
+    return dst
+
+
+def silu_and_mul(x):
+    x = _f(x)
+    T, two, I = x.shape
+    assert two == 2
+    out = np.empty((T, I), np.float32)
+    lib().orc_silu_and_mul(_p(x), _p(out), C.c_int(T), C.c_int(I))
+    return out
+
+
+def topk(probs, K):
+    probs = _f(probs)
+    rows, vocab = probs.shape
+    ids = np.empty((rows, K), np.int32)
+    vals = np.empty((rows, K), np.float32)
+    lib().orc_topk(_p(probs), _p(ids), _p(vals), C.c_int(rows), C.c_int(vocab), C.c_int(K))
+    return ids, vals
+
+
+def uniform_philox(seed, stream):
+    return float(lib().orc_uniform_philox(C.c_uint32(seed), C.c_uint32(stream)))
+
+
+def sampling(topk_id, topk_val, seq_len, finished, step, end_id, vocab):
+    """returns (out_id, new_seq_len, new_finished)"""
+    topk_id, topk_val = _i(topk_id), _f(topk_val)
+    bs, K = topk_id.shape
+    seq_len = _i(seq_len).copy()
+    fin = np.ascontiguousarray(finished, dtype=np.uint8).copy()
+    out = np.empty(bs, np.int32)
+    lib().orc_sampling(_p(topk_id), _p(topk_val), _p(seq_len), _p(fin), _p(out), C.c_int(bs), C.c_int(K),
+                       C.c_int(step), C.c_int(end_id), C.c_int(vocab))
+    return out, seq_len, fin.astype(bool)
+
+
+def linear_w8(x, wq, scale):
+    x = _f(x)
+    wq = np.ascontiguousarray(wq, dtype=np.int8)
+    scale = _f(scale)
+    M, K = x.shape
+    N = wq.shape[0]
+    y = np.empty((M, N), np.float32)
+    lib().orc_linear_w8(_p(x), _p(wq), _p(scale), _p(y), C.c_int(M), C.c_int(K), C.c_int(N))
+    return y
+
+
+def linear_w4(x, wq, scale, group):
+    x = _f(x)
+    wq = np.ascontiguousarray(wq, dtype=np.uint8)
+    scale = _f(scale)
+    M, K = x.shape
+    N = wq.shape[0]
+    y = np.empty((M, N), np.float32)
+    lib().orc_linear_w4(_p(x), _p(wq), _p(scale), _p(y), C.c_int(M), C.c_int(K), C.c_int(N), C.c_int(group))
+    return y
+
+
+class _Cfg(C.Structure):
+    _fields_ = [("head_num", C.c_int), ("kv_head_num", C.c_int), ("head_size", C.c_int),
+                ("inter_size", C.c_int), ("num_layers", C.c_int), ("vocab", C.c_int),
+                ("max_seq_len", C.c_int), ("rotary_dim", C.c_int),
+                ("rotary_base", C.c_float), ("rms_eps", C.c_float)]
+
+
+class _LayerW(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("attn_norm", "qkv", "qkv_bias", "o", "o_bias", "ffn_norm", "gate_up", "down")]
+
+
+def self_decoder(cfg, layers, hidden, k_cache, v_cache, step):
+    """cfg: dict with the orc_llama_cfg fields; layers: list of dicts of float32 arrays
+    (keys of orc_layer_weights; biases may be None).  Caches updated IN PLACE.
+    Returns the new hidden [bs, H]."""
+    hidden = _f(hidden).copy()
+    bs = hidden.shape[0]
+    c = _Cfg(**cfg)
+    H = c.head_num * c.head_size
+    QKV = (c.head_num + 2 * c.kv_head_num) * c.head_size
+    scratch = np.empty(bs * (2 * H + QKV + 3 * c.inter_size), np.float32)
+    keep = []
+    arr = (_LayerW * len(layers))()
+    for i, lw in enumerate(layers):
+        for name, _ in _LayerW._fields_:
+            a = lw.get(name)
+            if a is None:
+                setattr(arr[i], name, None)
+            else:
+                a = _f(a)
+                keep.append(a)
+                setattr(arr[i], name, a.ctypes.data)
+    assert k_cache.dtype == np.float32 and v_cache.dtype == np.float32
+    lib().orc_self_decoder(C.byref(c), arr, _p(hidden), _p(k_cache), _p(v_cache), C.c_int(bs), C.c_int(step),
+                           _p(scratch))
+    return hidden

@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/known_answers.json.
+
+The reference (chongchen1999/llm-inference-engine @ 2024_10_08) is CUDA-only and
+holds no output data files; what its own tests pin are (a) known answers written
+in comments / implied by trivially checkable inputs and (b) CPU checkers over
+inputs drawn from glibc rand().  This script records both kinds as DATA:
+  * hand-checkable known answers, each citing the reference file:line that
+    states them;
+  * for the rand()-driven tests, the exact inputs are regenerated with glibc
+    srand()/rand() (ctypes -> libc, the same generator the reference tests call)
+    and the expected outputs are computed with an independent exact method
+    (integer-valued float64 matmul / a numpy broadcast of the mask predicate),
+    then stored as SHA-256 digests plus a few sample values.
+Nothing here imports the oracle or reads /root/reference.
+Run:  python tests/golden/make_golden.py
+"""
+import ctypes
+import hashlib
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+libc = ctypes.CDLL("libc.so.6")
+libc.rand.restype = ctypes.c_int
+
+
+def glibc_rand_array(n, mod, add=0):
+    out = np.empty(n, np.int64)
+    r = libc.rand
+    for i in range(n):
+        out[i] = r() % mod + add
+    return out
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main():
+    g = {}
+
+    # includes/cal_padding_offset.cuh:8-15 (doc example in the header comment)
+    g["padding_offset_doc_example"] = {
+        "source": "src/kernels/includes/cal_padding_offset.cuh:8-15",
+        "lens": [4, 3, 5], "max_q_len": 5,
+        "cum_seqlens": [0, 4, 7, 12],
+        "padding_offset_packed": [0, 0, 0, 0, 1, 1, 1, 3, 3, 3, 3, 3],
+    }
+    # tests/unit_tests/test_cal_padding_offset.cu:62-64 (expected-result comment; lens 3,3,3)
+    g["padding_offset_test_comment"] = {
+        "source": "tests/unit_tests/test_cal_padding_offset.cu:62-64",
+        "lens": [3, 3, 3], "max_q_len": 5,
+        "cum_seqlens": [0, 3, 6, 9],
+        "padding_offset_packed": [0, 0, 0, 2, 2, 2, 4, 4, 4],
+    }
+    # tests/unit_tests/test_topk.cu:21-43: probs[i]=i over [2, 32000], K=5
+    g["topk_ramp"] = {
+        "source": "tests/unit_tests/test_topk.cu:21-43",
+        "rows": 2, "vocab": 32000, "K": 5,
+        "ids": [[31999, 31998, 31997, 31996, 31995]] * 2,
+        "vals": [[31999.0, 31998.0, 31997.0, 31996.0, 31995.0],
+                 [63999.0, 63998.0, 63997.0, 63996.0, 63995.0]],
+    }
+    # tests/unit_tests/test_silu_and_mul.cu:16-32,60-70: all-ones input -> silu(1)*1
+    g["swiglu_ones"] = {
+        "source": "tests/unit_tests/test_silu_and_mul.cu:16-32",
+        "batch": 128, "inter": 11008, "expected": 0.7310585786300049, "tol": 1e-6,
+    }
+    # tests/unit_tests/test_rmsnorm.cu:53-55,92-94: fp16 run uses all-ones x and gamma,
+    # eps 1e-6 -> 1/sqrt(1+1e-6) ~= 1 (tolerance 1e-3, test_rmsnorm.cu:33)
+    g["rmsnorm_ones"] = {
+        "source": "tests/unit_tests/test_rmsnorm.cu:42-118",
+        "tokens": 64, "hidden": 4096, "eps": 1e-6, "expected": 1.0, "tol": 1e-3,
+    }
+    # tests/unit_tests/test_rmsnorm.cu fp32 inputs: x=(i*i%3)+1 (per element index within the
+    # whole buffer), gamma=(i%3)+1; expectation = the checker formula evaluated in float64 here
+    T, H, eps = 64, 4096, 1e-6
+    idx = np.arange(T * H, dtype=np.int64)
+    x = ((idx * idx) % 3 + 1).astype(np.float64).reshape(T, H)
+    gam = (np.arange(H) % 3 + 1).astype(np.float64)
+    y = x * gam / np.sqrt((x * x).mean(axis=1, keepdims=True) + eps)
+    g["rmsnorm_fp32_pattern"] = {
+        "source": "tests/unit_tests/test_rmsnorm.cu:10-27,60-75",
+        "tokens": T, "hidden": H, "eps": eps, "tol": 1e-3,
+        "x": "(i*i%3)+1 over the flat buffer", "gamma": "(i%3)+1",
+        "sample_index": [0, 1, 2, 4095, 4096, 262143],
+        "sample_expected": [float(y.reshape(-1)[i]) for i in (0, 1, 2, 4095, 4096, 262143)],
+        "row_sums": [float(v) for v in y.sum(axis=1)[:4]],
+    }
+    # tests/unit_tests/test_add_residual.cu:10-21,40-50: out=(i%2)+1, resid=(i%2)+1 -> 2*((i%2)+1)
+    g["add_residual_pattern"] = {
+        "source": "tests/unit_tests/test_add_residual.cu:10-21",
+        "tokens": 16, "hidden": 4096, "expected": "2*((i%2)+1)",
+    }
+    # tests/unit_tests/test_transpose_and_remove_padding.cu:36-44: in[i]=i, [2,2,4,2], offs 0,0,2,2,2
+    bs, nh, S, hs = 2, 2, 4, 2
+    src = np.arange(bs * nh * S * hs, dtype=np.float32).reshape(bs, nh, S, hs)
+    toks = [(0, 0), (0, 1), (1, 0), (1, 1), (1, 2)]
+    exp = np.stack([src[b, :, s, :] for b, s in toks])
+    g["transpose_remove_padding"] = {
+        "source": "tests/unit_tests/test_transpose_and_remove_padding.cu:36-44",
+        "shape": [bs, nh, S, hs], "padding_offset": [0, 0, 2, 2, 2], "num_tokens": 5,
+        "expected": exp.reshape(-1).tolist(),
+    }
+    # tests/unit_tests/test_input_embedding.cu:15-23,50-60: table[i] = i / H  => out[t,:] == ids[t]
+    g["embedding_rowid"] = {
+        "source": "tests/unit_tests/test_input_embedding.cu:15-23",
+        "tokens": 64, "hidden": 4096, "vocab": 32000, "rule": "table[v,:]=v -> out[t,:]==ids[t]",
+    }
+    # tests/unit_tests/test_linear.cu:54-82: srand(233); weights then input, rand()%3; y = x.W^T
+    libc.srand(233)
+    Hh, M = 4096, 64
+    w = glibc_rand_array(Hh * Hh, 3).reshape(Hh, Hh)
+    xin = glibc_rand_array(M * Hh, 3).reshape(M, Hh)
+    yexp = (xin.astype(np.float64) @ w.astype(np.float64).T).astype(np.int32)
+    g["linear_srand233"] = {
+        "source": "tests/unit_tests/test_linear.cu:17-33,54-82",
+        "M": M, "K": Hh, "N": Hh, "srand": 233, "fill": "rand()%3, weights first then input",
+        "w_sha256_int8": sha(w.astype(np.int8)), "x_sha256_int8": sha(xin.astype(np.int8)),
+        "y_sha256_int32": sha(yexp), "y_first5": yexp.reshape(-1)[:5].tolist(),
+        "y_sum": int(yexp.astype(np.int64).sum()), "tol": 1e-3,
+    }
+    # tests/unit_tests/test_build_causal_mask.cu:13-31,66-72: default-seeded rand() lens
+    libc.srand(1)
+    bsz, mq, mk = 64, 128, 512
+    ql = glibc_rand_array(bsz, mq, 1)
+    kl = glibc_rand_array(bsz, mk, 1)
+    qq = np.arange(mq)[None, :, None]
+    kk = np.arange(mk)[None, None, :]
+    m = ((qq < ql[:, None, None]) & (kk < kl[:, None, None]) &
+         (kk <= qq + (kl - ql)[:, None, None])).astype(np.uint8)
+    g["causal_mask_rand"] = {
+        "source": "tests/unit_tests/test_build_causal_mask.cu:13-31,66-72",
+        "batch": bsz, "max_q_len": mq, "max_k_len": mk,
+        "q_lens": ql.tolist(), "k_lens": kl.tolist(),
+        "mask_sha256_uint8": sha(m), "ones": int(m.sum()),
+    }
+    with open(os.path.join(HERE, "known_answers.json"), "w") as f:
+        json.dump(g, f, indent=1, sort_keys=True)
+    print("wrote", os.path.join(HERE, "known_answers.json"))
+
+
+if __name__ == "__main__":
+    main()
