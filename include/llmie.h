@@ -1,0 +1,276 @@
+/*
+ * llmie.h -- C ABI of the MI355X-native Llama-2 decoder hot path.
+ *
+ * Drop-in boundary for chongchen1999/llm-inference-engine (reference @ 2024_10_08).
+ * The reference has no FFI of its own: its boundary is the set of C++ `launch*`
+ * templates in src/kernels/includes/ *.cuh plus the layer classes in
+ * src/layers/includes/ *.h.  Every entry point below replaces exactly one of those
+ * (cited per function, paths relative to the reference root); the C++ templates
+ * of the same names shipped in llm-inference-engine_amd/src/ are thin adaptors that
+ * unpack TensorWrapper<T> into these calls, so user_entry.cpp / examples/cpp build
+ * unchanged on top (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - plain pointers + sizes, no C++/torch types.  All data pointers are DEVICE
+ *     pointers (HBM) unless the name ends in _host.
+ *   - `dtype` selects the element type of every `void *` tensor of the call:
+ *     LLMIE_F32 (float) or LLMIE_F16 (IEEE half); accumulation is always fp32.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  No
+ *     entry point allocates, frees or synchronises: all of them are legal inside
+ *     hipStreamBeginCapture/EndCapture (hipGraph).
+ *   - return value: 0 on success, a negative llmie_status otherwise;
+ *     llmie_last_error() returns a thread-local message.  The C++ adaptors turn a
+ *     non-zero status into the reference's LLM_CHECK behaviour (std::runtime_error,
+ *     src/utils/macro.h:74-94).
+ *   - tensors are dense row-major; offsets are computed in 64-bit (the
+ *     reference's int32 offsets overflow for the 7B KV cache at batch >= 8).
+ */
+#ifndef LLMIE_H
+#define LLMIE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LLMIE_ABI_VERSION 1
+
+typedef enum { LLMIE_F32 = 0, LLMIE_F16 = 1 } llmie_dtype;
+
+typedef enum {
+    LLMIE_OK = 0,
+    LLMIE_ERR_INVALID_ARG = -1,   /* NULL pointer, non-positive size, shape mismatch */
+    LLMIE_ERR_UNSUPPORTED = -2,   /* shape/dtype outside what the kernels implement   */
+    LLMIE_ERR_LAUNCH = -3,        /* hipGetLastError() != hipSuccess after the launch */
+    LLMIE_ERR_WORKSPACE = -4      /* caller-provided workspace too small              */
+} llmie_status;
+
+typedef void *llmie_stream; /* hipStream_t */
+
+int llmie_abi_version(void);
+const char *llmie_last_error(void);
+/* "gfx950" -- the only architecture this library carries code objects for */
+const char *llmie_target_arch(void);
+
+/* ------------------------------------------------------------------------- */
+/* 1. per-kernel entry points (one per reference launcher)                   */
+/* ------------------------------------------------------------------------- */
+
+/* replaces launchInputEmbedding        src/kernels/input_embedding.cu:24-51
+ * out[t,:] = table[ids[t],:]; ids outside [0,vocab) -> row of zeros is NOT written
+ * (status LLMIE_OK; the row is left untouched, as the reference would fault). */
+int llmie_input_embedding(const int32_t *ids, const void *table, void *out,
+                          int num_tokens, int hidden, int vocab,
+                          llmie_dtype dtype, llmie_stream stream);
+
+/* replaces launchCalPaddingOffset      src/kernels/cal_padding_offset.cu:45-70
+ * padding_offset is packed (first sum(lens) ints written), cum_seqlens has batch+1 ints */
+int llmie_cal_padding_offset(int32_t *padding_offset, int32_t *cum_seqlens,
+                             const int32_t *input_lengths, int batch, int max_q_len,
+                             llmie_stream stream);
+
+/* replaces launchBuildCausalMasks      src/kernels/build_causal_mask.cu:25-42 */
+int llmie_build_causal_mask(void *mask, const int32_t *q_lens, const int32_t *k_lens,
+                            int batch, int max_q_len, int max_k_len,
+                            llmie_dtype dtype, llmie_stream stream);
+
+/* replaces launchRMSNorm               src/kernels/rmsnorm.cu:130-159
+ * resid (nullable) = x;  x = x * gamma * rsqrt(mean(x^2)+eps)  in place */
+int llmie_rmsnorm(void *x, void *resid, const void *gamma, float eps,
+                  int num_tokens, int hidden, llmie_dtype dtype, llmie_stream stream);
+
+/* replaces launchFusedAddBiasResidualAndRMSNorm  src/kernels/add_residual_and_rmsnorm.cu:170-201
+ * out += resid; resid = out; out += bias (nullable); out = gamma*out*rsqrt(mean(out^2)+eps) */
+int llmie_fused_add_bias_residual_rmsnorm(void *resid, void *out, const void *bias,
+                                          const void *gamma, float eps,
+                                          int num_tokens, int hidden,
+                                          llmie_dtype dtype, llmie_stream stream);
+
+/* replaces launchAddResidual           src/kernels/add_residual.cu:51-76     out += resid */
+int llmie_add_residual(const void *resid, void *out, int num_tokens, int hidden,
+                       llmie_dtype dtype, llmie_stream stream);
+
+/* replaces launchLinearGemm            src/kernels/linear.cu:10-87 (+ cublas_utils.cpp:29-93)
+ * trans_b != 0: y[M,N] = x[M,K] . W[N,K]^T ; trans_b == 0: y = x . W[K,N].
+ * bias (nullable, [N]) and residual (nullable, [M,N], may alias y) are fused epilogues the
+ * reference does in separate kernels; pass NULL for the plain reference semantics. */
+int llmie_linear(const void *x, const void *w, void *y, int M, int K, int N, int trans_b,
+                 const void *bias, const void *residual,
+                 llmie_dtype dtype, llmie_stream stream);
+
+/* replaces launchLinearStridedBatchGemm src/kernels/linear.cu:89-158 (+ cublas_utils.cpp:95-154)
+ * per batch i: C_i[m,n] = A_i[m,k] . B_i  (B_i is [n,k] if trans_b else [k,n]); dense strides */
+int llmie_batched_gemm(const void *a, const void *b, void *c, int batch, int m, int n, int k,
+                       int trans_b, llmie_dtype dtype, llmie_stream stream);
+
+/* replaces launchFusedQKVAddBiasAndTransposeAndRope  src/kernels/qkv_bias_and_rope.cu:86-138
+ * QKV[T, nh+2kvh, hs] -> q[bs,nh,S,hs], k/v[bs,kvh,S,hs]; RoPE at history_len[b]+local_token */
+int llmie_qkv_bias_transpose_rope(void *q, void *k, void *v, const void *qkv, const void *bias,
+                                  const int32_t *padding_offset, const int32_t *history_len,
+                                  int batch, int seq_len, int num_tokens,
+                                  int head_num, int kv_head_num, int head_size,
+                                  int rotary_dim, float rotary_base,
+                                  llmie_dtype dtype, llmie_stream stream);
+
+/* replaces launchRope                  src/kernels/rope.cu:60-98
+ * in place on qkv[bs, nh+2kvh, hs]; position = step-1.  If step_dev != NULL the position is
+ * read from that device int (graph replay with a moving step) and `step` is ignored. */
+int llmie_rope_decode(void *qkv, int batch, int head_num, int kv_head_num, int head_size,
+                      int step, const int32_t *step_dev, int rotary_dim, float rotary_base,
+                      llmie_dtype dtype, llmie_stream stream);
+
+/* replaces launchDecoderMaskedMultiHeadAttention   src/kernels/decoder_self_attention.cu:211-270
+ * qkv[bs, nh+2kvh, hs] (+bias) ; caches [L,bs,kvh,max_seq,hs]; out [bs, nh*hs].
+ * Appends k,v at slot step-1 of `layer`, then attends over t < step.
+ * workspace: llmie_decoder_mha_workspace_bytes() bytes (split-KV partials). */
+size_t llmie_decoder_mha_workspace_bytes(int batch, int head_num, int head_size, int max_seq_len);
+int llmie_decoder_mha(const void *qkv, const void *qkv_bias, void *k_cache, void *v_cache,
+                      void *out, int layer, int batch, int head_num, int kv_head_num,
+                      int head_size, int max_seq_len, int step, const int32_t *step_dev,
+                      void *workspace, size_t workspace_bytes,
+                      llmie_dtype dtype, llmie_stream stream);
+
+/* replaces launchConcatKVCache         src/kernels/concat_past_kv.cu:44-89  (one call = K or V) */
+int llmie_concat_kv(const void *src, void *cache, const int32_t *cur_len,
+                    const int32_t *history_len, int layer, int batch, int kv_head_num,
+                    int max_q_len, int max_seq_len, int head_size,
+                    llmie_dtype dtype, llmie_stream stream);
+
+/* replaces launchRepeatKVCache         src/kernels/repeat_kv.cu:51-106      (one call = K or V) */
+int llmie_repeat_kv(const void *cache, void *dst, const int32_t *ctx_len, int layer, int batch,
+                    int head_num, int kv_head_num, int max_k_len, int max_seq_len, int head_size,
+                    llmie_dtype dtype, llmie_stream stream);
+
+/* replaces launchFusedScaleMaskAndSoftmax  src/kernels/scale_and_mask_and_softmax.cu:213-341
+ * out may alias qk */
+int llmie_scale_mask_softmax(const void *qk, const void *mask, void *out, float scale,
+                             int batch, int head_num, int q_len, int k_len,
+                             llmie_dtype dtype, llmie_stream stream);
+
+/* replaces launchFusedTransposeAndRemovePadding  src/kernels/transpose_and_remove_padding.cu:45-74 */
+int llmie_transpose_remove_padding(const void *src, void *dst, const int32_t *padding_offset,
+                                   int num_tokens, int batch, int seq_len, int head_num,
+                                   int head_size, llmie_dtype dtype, llmie_stream stream);
+
+/* replaces launchSiluAndMul            src/kernels/silu_and_mul.cu:61-82   in[T,2,I] -> out[T,I] */
+int llmie_silu_and_mul(const void *in, void *out, int num_tokens, int inter,
+                       llmie_dtype dtype, llmie_stream stream);
+
+/* replaces launchTopKForBeamSearch     src/kernels/topk.cu:104-140
+ * probs[rows,vocab] -> ids/vals[rows,K] descending (ties: lower id first).
+ * tmp_ids/tmp_vals: [rows, blocks_per_row, K] scratch (the reference's round-1 buffers);
+ * 1 <= K <= 32, 1 <= blocks_per_row <= 64. */
+int llmie_topk(const void *probs, int32_t *tmp_ids, void *tmp_vals, int32_t *ids, void *vals,
+               int rows, int vocab, int K, int blocks_per_row,
+               llmie_dtype dtype, llmie_stream stream);
+
+/* replaces launchSampling              src/kernels/sampling.cu:73-102
+ * topk_val is NOT modified (the reference overwrites it with the exponentials).
+ * finished is a byte per sequence (C++ bool).  Uniform draw: Philox4x32-10(seed=step, stream=b).
+ * If step_dev != NULL the seed is read from that device int. */
+int llmie_sampling(const int32_t *topk_id, const void *topk_val, int32_t *seq_len,
+                   uint8_t *finished, int32_t *out_id, int batch, int K, int step,
+                   const int32_t *step_dev, int end_id, int vocab,
+                   llmie_dtype dtype, llmie_stream stream);
+
+/* ------------------------------------------------------------------------- */
+/* 2. weight-only quantised / fp8 linears (reference: planned only,           */
+/*    README.md:36-39, linear.cuh:12 TODO)                                    */
+/* ------------------------------------------------------------------------- */
+
+/* y[M,N] = x[M,K] . (scale[n]*Wq[n,k])^T ; x,y,scale,bias fp16; Wq int8 row-major [N,K] */
+int llmie_linear_w8a16(const void *x, const int8_t *wq, const void *scale, void *y,
+                       int M, int K, int N, const void *bias, const void *residual,
+                       llmie_stream stream);
+/* int4: two nibbles per byte (low nibble = even k), value = nibble-8, scale[n, k/group] fp16 */
+int llmie_linear_w4a16(const void *x, const uint8_t *wq, const void *scale, void *y,
+                       int M, int K, int N, int group, const void *bias, const void *residual,
+                       llmie_stream stream);
+/* fp8 e4m3 (OCP) weights [N,K] with per-row fp32 scale; x fp16 is quantised per token to e4m3
+ * on the fly (scale = amax/448); fp32 accumulate on the fp8 MFMA; y fp16 */
+int llmie_linear_fp8(const void *x, const uint8_t *w_fp8, const float *w_scale, void *y,
+                     int M, int K, int N, const void *bias, const void *residual,
+                     void *workspace, size_t workspace_bytes, llmie_stream stream);
+size_t llmie_linear_fp8_workspace_bytes(int M, int K);
+/* offline quantisers (device side): w fp16 [N,K] -> int8/int4/fp8 + scales */
+int llmie_quantize_w8(const void *w, int8_t *wq, void *scale, int N, int K, llmie_stream stream);
+int llmie_quantize_w4(const void *w, uint8_t *wq, void *scale, int N, int K, int group,
+                      llmie_stream stream);
+int llmie_quantize_fp8(const void *w, uint8_t *wq, float *scale, int N, int K, llmie_stream stream);
+
+/* ------------------------------------------------------------------------- */
+/* 3. fused decoder engine (what LlamaSelfDecoder<T>::forward and             */
+/*    LlamaModel<T>::generateNextToken run on; src/layers/self_decoder.cpp:24-122, */
+/*    src/models/llama/llama.cpp:219-318)                                     */
+/* ------------------------------------------------------------------------- */
+
+typedef enum {
+    LLMIE_W_F16 = 0,     /* fp16 weights [N,K]                                   */
+    LLMIE_W_INT8 = 1,    /* int8 [N,K] + fp16 per-row scale                      */
+    LLMIE_W_INT4 = 2,    /* packed int4 [N,K/2] + fp16 scale per (row, group)    */
+    LLMIE_W_FP8 = 3,     /* e4m3 [N,K] + fp32 per-row scale                      */
+    LLMIE_W_F32 = 4      /* fp32 weights (dtype LLMIE_F32 engines only)          */
+} llmie_weight_format;
+
+typedef struct {
+    const void *data;      /* [N,K] in the format's storage */
+    const void *scale;     /* NULL for F16/F32 */
+    const void *bias;      /* nullable, [N], activation dtype */
+} llmie_matrix;
+
+typedef struct {
+    const void *attn_norm_gamma;   /* [H] */
+    llmie_matrix qkv;              /* N=(nh+2kvh)*hs, K=H   (self_attn.qkv, layer_weights.cpp:28-31) */
+    llmie_matrix o;                /* N=H, K=H                                                     */
+    const void *ffn_norm_gamma;    /* [H] */
+    llmie_matrix gate_up;          /* N=2I, K=H  rows [0,I)=gate, [I,2I)=up (layer_weights.cpp:41-44) */
+    llmie_matrix down;             /* N=H, K=I */
+} llmie_layer_weights;
+
+typedef struct {
+    int head_num, kv_head_num, head_size, inter_size, num_layers, vocab_size;
+    int max_seq_len, max_batch;
+    int rotary_dim;
+    float rotary_base, rms_eps;
+    llmie_dtype dtype;             /* activation / KV dtype */
+    llmie_weight_format wfmt;      /* storage of the 4 big matrices per layer */
+    int int4_group;                /* group size for LLMIE_W_INT4 */
+} llmie_decoder_config;
+
+typedef struct llmie_decoder llmie_decoder; /* opaque */
+
+/* Workspace is caller-owned device memory (no allocation inside). */
+size_t llmie_decoder_workspace_bytes(const llmie_decoder_config *cfg);
+/* layers[num_layers] is copied (pointers only). Returns NULL on invalid config. */
+llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg,
+                                    const llmie_layer_weights *layers,
+                                    void *workspace, size_t workspace_bytes);
+void llmie_decoder_destroy(llmie_decoder *dec);
+
+/* One decode step through all layers, in place semantics of LlamaSelfDecoder::forward:
+ * hidden_in[bs,H] -> hidden_out[bs,H] (may alias).  Caches [L, batch, kvh, max_seq, hs].
+ * step = context length INCLUDING the new token (reference `step`); if step_dev != NULL it is
+ * read on the device (one int shared by the batch) so a captured graph can be replayed. */
+int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, void *hidden_out,
+                          void *k_cache, void *v_cache, int batch, int step,
+                          const int32_t *step_dev, llmie_stream stream);
+
+/* LM head + top-k + sampling tail (llama.cpp:247-318): final RMSNorm(gamma) -> logits =
+ * x . lm_head[V,H]^T -> top-K -> sample.  logits[bs,V] and topk buffers caller-owned. */
+int llmie_lm_head_sample(llmie_decoder *dec, void *hidden /* [bs,H], normalised in place */,
+                         const void *final_norm_gamma, const llmie_matrix *lm_head,
+                         llmie_weight_format lm_fmt, void *logits,
+                         int32_t *tmp_ids, void *tmp_vals, int32_t *topk_ids, void *topk_vals,
+                         int K, int blocks_per_row, int32_t *seq_len, uint8_t *finished,
+                         int32_t *out_ids, int batch, int step, const int32_t *step_dev,
+                         int end_id, llmie_stream stream);
+
+/* device-side helper for graph replay: *step_dev += 1 */
+int llmie_advance_step(int32_t *step_dev, llmie_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LLMIE_H */

@@ -1,0 +1,256 @@
+"""llm-inference-engine_amd -- MI355X-native Llama-2 decoder hot path.
+
+Python side = plumbing only: it loads the in-tree C-ABI library
+(lib/libllmie.so, built by build.py with hipcc for gfx950; see include/llmie.h)
+through ctypes and hands it device pointers of torch tensors.  There is NO CPU or
+PyTorch fallback: if the library is missing or a call fails, an exception is raised.
+
+The directory name carries a hyphen (it mirrors the reference repo's name), so import
+it with importlib (tests/conftest.py, bench.py and __graft_entry__.py show how) under
+the module name ``llmie_amd``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libllmie.so")
+
+F32, F16 = 0, 1
+W_F16, W_INT8, W_INT4, W_FP8, W_F32 = 0, 1, 2, 3, 4
+
+_lib = None
+
+
+class LlmieError(RuntimeError):
+    pass
+
+
+def build(force=False, jobs=4):
+    """Compile every HIP source for gfx950 (hipcc) into lib/libllmie.so."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("llmie_amd_build", os.path.join(_HERE, "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build(force=force, jobs=jobs)
+
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> argtypes (restype int unless listed in _RESTYPES); mirrors include/llmie.h
+_SIGS = {
+    "llmie_input_embedding": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "llmie_cal_padding_offset": [_vp, _vp, _vp, _i, _i, _vp],
+    "llmie_build_causal_mask": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "llmie_rmsnorm": [_vp, _vp, _vp, _f, _i, _i, _i, _vp],
+    "llmie_fused_add_bias_residual_rmsnorm": [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp],
+    "llmie_add_residual": [_vp, _vp, _i, _i, _i, _vp],
+    "llmie_linear": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],
+    "llmie_batched_gemm": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "llmie_qkv_bias_transpose_rope": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "llmie_rope_decode": [_vp, _i, _i, _i, _i, _i, _vp, _i, _f, _i, _vp],
+    "llmie_decoder_mha_workspace_bytes": [_i, _i, _i, _i],
+    "llmie_decoder_mha": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp],
+    "llmie_concat_kv": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "llmie_repeat_kv": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "llmie_scale_mask_softmax": [_vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp],
+    "llmie_transpose_remove_padding": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "llmie_silu_and_mul": [_vp, _vp, _i, _i, _i, _vp],
+    "llmie_topk": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "llmie_sampling": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp],
+    "llmie_linear_w8a16": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "llmie_linear_w4a16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "llmie_linear_fp8": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp],
+    "llmie_linear_fp8_workspace_bytes": [_i, _i],
+    "llmie_quantize_w8": [_vp, _vp, _vp, _i, _i, _vp],
+    "llmie_quantize_w4": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "llmie_quantize_fp8": [_vp, _vp, _vp, _i, _i, _vp],
+    "llmie_decoder_workspace_bytes": [_vp],
+    "llmie_decoder_create": [_vp, _vp, _vp, _sz],
+    "llmie_decoder_destroy": [_vp],
+    "llmie_decoder_forward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
+    "llmie_lm_head_sample": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp,
+                             _i, _vp],
+    "llmie_advance_step": [_vp, _vp],
+    "llmie_abi_version": [],
+    "llmie_last_error": [],
+    "llmie_target_arch": [],
+}
+_RESTYPES = {
+    "llmie_decoder_mha_workspace_bytes": _sz,
+    "llmie_linear_fp8_workspace_bytes": _sz,
+    "llmie_decoder_workspace_bytes": _sz,
+    "llmie_decoder_create": _vp,
+    "llmie_decoder_destroy": None,
+    "llmie_last_error": C.c_char_p,
+    "llmie_target_arch": C.c_char_p,
+}
+
+EXPORTS = tuple(sorted(_SIGS))
+
+
+def lib():
+    """The loaded C-ABI library.  Raises (never falls back) when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LlmieError(
+                "HIP library %s is missing: run `python llm-inference-engine_amd/build.py` "
+                "(or __graft_entry__.build()).  There is no CPU fallback." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(l, name)  # AttributeError if the ABI lost a symbol
+            fn.argtypes = args
+            fn.restype = _RESTYPES.get(name, C.c_int)
+        if l.llmie_abi_version() != 1:
+            raise LlmieError("libllmie.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise LlmieError("%s failed (%d): %s" % (what, rc, lib().llmie_last_error().decode()))
+
+
+def _dt(t):
+    import torch
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.float16:
+        return F16
+    raise LlmieError("unsupported dtype %s" % t.dtype)
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensors only"
+    return t.data_ptr()
+
+
+def _st():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ------------------------------------------------------------------ per-kernel wrappers
+def input_embedding(ids, table, out):
+    _check(lib().llmie_input_embedding(_p(ids), _p(table), _p(out), ids.numel(), table.shape[1], table.shape[0],
+                                       _dt(table), _st()), "input_embedding")
+    return out
+
+
+def cal_padding_offset(padding_offset, cum_seqlens, lens):
+    _check(lib().llmie_cal_padding_offset(_p(padding_offset), _p(cum_seqlens), _p(lens), lens.numel(),
+                                          padding_offset.shape[1], _st()), "cal_padding_offset")
+
+
+def build_causal_mask(mask, q_lens, k_lens):
+    _check(lib().llmie_build_causal_mask(_p(mask), _p(q_lens), _p(k_lens), mask.shape[0], mask.shape[1],
+                                         mask.shape[2], _dt(mask), _st()), "build_causal_mask")
+    return mask
+
+
+def rmsnorm(x, resid, gamma, eps):
+    _check(lib().llmie_rmsnorm(_p(x), _p(resid), _p(gamma), eps, x.shape[0], x.shape[1], _dt(x), _st()), "rmsnorm")
+
+
+def fused_add_bias_residual_rmsnorm(resid, out, bias, gamma, eps):
+    _check(lib().llmie_fused_add_bias_residual_rmsnorm(_p(resid), _p(out), _p(bias), _p(gamma), eps, out.shape[0],
+                                                       out.shape[1], _dt(out), _st()),
+           "fused_add_bias_residual_rmsnorm")
+
+
+def add_residual(resid, out):
+    _check(lib().llmie_add_residual(_p(resid), _p(out), out.shape[0], out.shape[1], _dt(out), _st()), "add_residual")
+
+
+def linear(x, w, y, trans_b=True, bias=None, residual=None):
+    M, K = x.shape[0], x.numel() // x.shape[0]
+    N = y.numel() // y.shape[0]
+    _check(lib().llmie_linear(_p(x), _p(w), _p(y), M, K, N, int(trans_b), _p(bias), _p(residual), _dt(x), _st()),
+           "linear")
+    return y
+
+
+def batched_gemm(a, b, c, trans_b):
+    bs, nh, m, k = a.shape
+    n = c.shape[3]
+    _check(lib().llmie_batched_gemm(_p(a), _p(b), _p(c), bs * nh, m, n, k, int(trans_b), _dt(a), _st()),
+           "batched_gemm")
+    return c
+
+
+def qkv_bias_transpose_rope(q, k, v, qkv, bias, padding_offset, history_len, rotary_dim, rotary_base):
+    bs, nh, S, hs = q.shape
+    _check(lib().llmie_qkv_bias_transpose_rope(_p(q), _p(k), _p(v), _p(qkv), _p(bias), _p(padding_offset),
+                                               _p(history_len), bs, S, qkv.shape[0], nh, k.shape[1], hs,
+                                               rotary_dim, rotary_base, _dt(qkv), _st()), "qkv_bias_transpose_rope")
+
+
+def rope_decode(qkv, head_num, kv_head_num, step, rotary_dim, rotary_base, step_dev=None):
+    _check(lib().llmie_rope_decode(_p(qkv), qkv.shape[0], head_num, kv_head_num, qkv.shape[2], step, _p(step_dev),
+                                   rotary_dim, rotary_base, _dt(qkv), _st()), "rope_decode")
+
+
+def decoder_mha_workspace_bytes(batch, head_num, head_size, max_seq_len):
+    return lib().llmie_decoder_mha_workspace_bytes(batch, head_num, head_size, max_seq_len)
+
+
+def decoder_mha(qkv, qkv_bias, k_cache, v_cache, out, layer, head_num, kv_head_num, step, workspace,
+                step_dev=None):
+    bs, _, hs = qkv.shape
+    max_seq = k_cache.shape[3]
+    _check(lib().llmie_decoder_mha(_p(qkv), _p(qkv_bias), _p(k_cache), _p(v_cache), _p(out), layer, bs, head_num,
+                                   kv_head_num, hs, max_seq, step, _p(step_dev), _p(workspace),
+                                   0 if workspace is None else workspace.numel() * workspace.element_size(),
+                                   _dt(qkv), _st()), "decoder_mha")
+    return out
+
+
+def concat_kv(src, cache, cur_len, history_len, layer):
+    bs, kvh, max_q, hs = src.shape
+    _check(lib().llmie_concat_kv(_p(src), _p(cache), _p(cur_len), _p(history_len), layer, bs, kvh, max_q,
+                                 cache.shape[3], hs, _dt(src), _st()), "concat_kv")
+
+
+def repeat_kv(cache, dst, ctx_len, layer):
+    bs, nh, max_k, hs = dst.shape
+    _check(lib().llmie_repeat_kv(_p(cache), _p(dst), _p(ctx_len), layer, bs, nh, cache.shape[2], max_k,
+                                 cache.shape[3], hs, _dt(dst), _st()), "repeat_kv")
+
+
+def scale_mask_softmax(qk, mask, out, scale):
+    bs, nh, ql, kl = qk.shape
+    _check(lib().llmie_scale_mask_softmax(_p(qk), _p(mask), _p(out), scale, bs, nh, ql, kl, _dt(qk), _st()),
+           "scale_mask_softmax")
+    return out
+
+
+def transpose_remove_padding(src, padding_offset, dst):
+    bs, nh, S, hs = src.shape
+    _check(lib().llmie_transpose_remove_padding(_p(src), _p(dst), _p(padding_offset), dst.shape[0], bs, S, nh, hs,
+                                                _dt(src), _st()), "transpose_remove_padding")
+    return dst
+
+
+def silu_and_mul(x, out):
+    _check(lib().llmie_silu_and_mul(_p(x), _p(out), x.shape[0], x.shape[2], _dt(x), _st()), "silu_and_mul")
+    return out
+
+
+def topk(probs, tmp_ids, tmp_vals, ids, vals, blocks_per_row=8):
+    rows, vocab = probs.shape
+    K = ids.shape[-1]
+    _check(lib().llmie_topk(_p(probs), _p(tmp_ids), _p(tmp_vals), _p(ids), _p(vals), rows, vocab, K, blocks_per_row,
+                            _dt(probs), _st()), "topk")
+
+
+def sampling(topk_id, topk_val, seq_len, finished, out_id, step, end_id, vocab, step_dev=None):
+    bs, K = topk_id.shape
+    _check(lib().llmie_sampling(_p(topk_id), _p(topk_val), _p(seq_len), _p(finished), _p(out_id), bs, K, step,
+                                _p(step_dev), end_id, vocab, _dt(topk_val), _st()), "sampling")
+
+
+def advance_step(step_dev):
+    _check(lib().llmie_advance_step(_p(step_dev), _st()), "advance_step")

@@ -1,0 +1,393 @@
+// Fused decode attention for gfx950: llmie_decoder_mha
+// (replaces launchDecoderMaskedMultiHeadAttention, decoder_self_attention.cu:56-270).
+//
+// Math (reference fp32 kernel, with the batch-stride / step<=head_size / GQA-race defects of
+// SURVEY 9-K4 fixed):   q,k,v (+bias)  ->  cache[layer,b,g,step-1,:] = k,v  ->
+//   logit[t] = (q . K[t]) / sqrt(hs), t < step  ->  p = exp(l - max) / (sum + 1e-6)  ->  out = sum p V.
+//
+// Design: flash-decoding.  The KV range [0, step) of one (batch, kv-head) is split into chunks of
+// CHUNK tokens; one 256-thread workgroup per chunk streams its K and V rows with 16-byte loads
+// straight to VGPRs (a wave instruction covers 64/LPT whole rows = 1 KiB contiguous; every load
+// of the chunk is issued before the first use), keeps all REP query heads of the kv head in
+// registers (GQA reads each K/V byte once), does the softmax with wave64 shuffles, and writes an
+// (m, l, o[hs]) partial.  A second tiny kernel merges the partials.  bs*kvh*splits workgroups
+// fill the 256 CUs even at batch 1 (7B, S=2048: 32*16 = 512 workgroups).
+// HBM-bound: algorithmic bytes = 2 * step * kvh * hs * sizeof(T) per sequence.
+#include "device_utils.cuh"
+
+namespace llmie {
+
+constexpr int kAttnWaves = 4;
+constexpr int kAttnG = 8;  // K (and V) 16-byte loads in flight per lane
+
+template <typename T, int HS> struct AttnGeom {
+    static constexpr int N = Vec16<T>::n;            // elements per 16-byte load
+    static constexpr int LPT = HS / N;               // lanes per token row
+    static constexpr int TPW = 64 / LPT;             // token rows per wave instruction
+    static constexpr int CHUNK = kAttnWaves * kAttnG * TPW;  // tokens per workgroup
+};
+
+__host__ __device__ inline int attn_min_chunk() { return 32; }
+
+template <typename T, int HS, int REP>
+__global__ __launch_bounds__(256) void decode_attn_split_kernel(
+    const T *__restrict__ qkv, const T *__restrict__ qkv_bias, T *k_cache, T *v_cache,
+    float *__restrict__ part, T *__restrict__ out, int head_num, int kv_head_num, int max_seq_len,
+    int step_arg, const int32_t *__restrict__ step_dev, int max_splits) {
+    using G = AttnGeom<T, HS>;
+    using V = typename Vec16<T>::type;
+    constexpr int N = G::N, LPT = G::LPT, TPW = G::TPW, CHUNK = G::CHUNK;
+    static_assert(HS % N == 0 && LPT >= 1 && LPT <= 64 && (LPT & (LPT - 1)) == 0, "head size");
+
+    const int step = step_dev ? *step_dev : step_arg;
+    const int split = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+    const int t0 = split * CHUNK;
+    if (t0 >= step) return;  // whole workgroup exits together
+    const int t_end = min(step, t0 + CHUNK);
+    const int nsplits = (step + CHUNK - 1) / CHUNK;
+    const int batch = gridDim.z;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPT, dl = lane % LPT;
+    const int qkv_heads = head_num + 2 * kv_head_num;
+    const float scale = rsqrtf(static_cast<float>(HS));
+
+    const T *row = qkv + static_cast<size_t>(b) * qkv_heads * HS;
+    // q for the REP heads of this kv head, pre-scaled, fp32
+    float qf[REP][N];
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+        const int h = g * REP + r;
+        V qv = reinterpret_cast<const V *>(row + static_cast<size_t>(h) * HS)[dl];
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            float f = to_f32(qv[e]);
+            if (qkv_bias) f += to_f32(qkv_bias[static_cast<size_t>(h) * HS + dl * N + e]);
+            qf[r][e] = f * scale;
+        }
+    }
+    const size_t head_off = (static_cast<size_t>(b) * kv_head_num + g) * max_seq_len * HS;
+    T *kc = k_cache + head_off;
+    T *vc = v_cache + head_off;
+    const int t_new = step - 1;
+
+    // ---- issue every K and V load of this wave's token range ----
+    V kv[kAttnG], vv[kAttnG];
+    int tok[kAttnG];
+#pragma unroll
+    for (int i = 0; i < kAttnG; ++i) {
+        const int t = t0 + (wave * kAttnG + i) * TPW + sub;
+        tok[i] = t;
+        if (t < t_end && t != t_new) kv[i] = load_nt(reinterpret_cast<const V *>(kc + static_cast<size_t>(t) * HS) + dl);
+    }
+#pragma unroll
+    for (int i = 0; i < kAttnG; ++i) {
+        const int t = tok[i];
+        if (t < t_end && t != t_new) vv[i] = load_nt(reinterpret_cast<const V *>(vc + static_cast<size_t>(t) * HS) + dl);
+    }
+    // the token of this step comes from the qkv buffer (+bias) and is appended to the cache
+#pragma unroll
+    for (int i = 0; i < kAttnG; ++i) {
+        if (tok[i] == t_new) {
+            const int hk = head_num + g, hv = head_num + kv_head_num + g;
+            V kn = reinterpret_cast<const V *>(row + static_cast<size_t>(hk) * HS)[dl];
+            V vn = reinterpret_cast<const V *>(row + static_cast<size_t>(hv) * HS)[dl];
+            if (qkv_bias) {
+#pragma unroll
+                for (int e = 0; e < N; ++e) {
+                    kn[e] = from_f32<T>(to_f32(kn[e]) + to_f32(qkv_bias[static_cast<size_t>(hk) * HS + dl * N + e]));
+                    vn[e] = from_f32<T>(to_f32(vn[e]) + to_f32(qkv_bias[static_cast<size_t>(hv) * HS + dl * N + e]));
+                }
+            }
+            kv[i] = kn;
+            vv[i] = vn;
+            reinterpret_cast<V *>(kc + static_cast<size_t>(t_new) * HS)[dl] = kn;
+            reinterpret_cast<V *>(vc + static_cast<size_t>(t_new) * HS)[dl] = vn;
+        }
+    }
+
+    // ---- logits ----
+    float lg[REP][kAttnG];
+    float mx[REP];
+#pragma unroll
+    for (int r = 0; r < REP; ++r) mx[r] = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < kAttnG; ++i) {
+        const bool valid = tok[i] < t_end;
+#pragma unroll
+        for (int r = 0; r < REP; ++r) {
+            float d = 0.f;
+            if (valid) {
+#pragma unroll
+                for (int e = 0; e < N; ++e) d = fmaf(qf[r][e], to_f32(kv[i][e]), d);
+            }
+            d = group_sum<LPT>(d);
+            lg[r][i] = valid ? d : -INFINITY;
+            mx[r] = fmaxf(mx[r], lg[r][i]);
+        }
+    }
+    // wave max over the TPW token slots (lanes differing in sub)
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+#pragma unroll
+        for (int o = LPT; o < 64; o <<= 1) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o, 64));
+    }
+    // ---- softmax numerators and P.V ----
+    float acc[REP][N], ls[REP];
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+        ls[r] = 0.f;
+#pragma unroll
+        for (int e = 0; e < N; ++e) acc[r][e] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < kAttnG; ++i) {
+        const bool valid = tok[i] < t_end;
+        if (valid) {
+#pragma unroll
+            for (int r = 0; r < REP; ++r) {
+                const float p = __expf(lg[r][i] - mx[r]);
+                ls[r] += p;
+#pragma unroll
+                for (int e = 0; e < N; ++e) acc[r][e] = fmaf(p, to_f32(vv[i][e]), acc[r][e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+#pragma unroll
+        for (int o = LPT; o < 64; o <<= 1) {
+            ls[r] += __shfl_xor(ls[r], o, 64);
+#pragma unroll
+            for (int e = 0; e < N; ++e) acc[r][e] += __shfl_xor(acc[r][e], o, 64);
+        }
+    }
+    // ---- merge the 4 waves through LDS ----
+    __shared__ float s_m[REP][kAttnWaves], s_l[REP][kAttnWaves];
+    __shared__ float s_o[REP][kAttnWaves][HS];
+    if (sub == 0) {
+#pragma unroll
+        for (int r = 0; r < REP; ++r) {
+#pragma unroll
+            for (int e = 0; e < N; ++e) s_o[r][wave][dl * N + e] = acc[r][e];
+            if (dl == 0) {
+                s_m[r][wave] = mx[r];
+                s_l[r][wave] = ls[r];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < REP * HS; i += 256) {
+        const int r = i / HS, d = i - r * HS;
+        float M = s_m[r][0];
+#pragma unroll
+        for (int w = 1; w < kAttnWaves; ++w) M = fmaxf(M, s_m[r][w]);
+        float L = 0.f, o = 0.f;
+#pragma unroll
+        for (int w = 0; w < kAttnWaves; ++w) {
+            const float f = (s_m[r][w] == -INFINITY) ? 0.f : __expf(s_m[r][w] - M);
+            L += f * s_l[r][w];
+            o += f * s_o[r][w][d];
+        }
+        const int h = g * REP + r;
+        if (nsplits == 1) {
+            out[(static_cast<size_t>(b) * head_num + h) * HS + d] = from_f32<T>(o / (L + 1e-6f));
+        } else {
+            float *p = part + ((static_cast<size_t>(b) * head_num + h) * max_splits + split) * (HS + 2);
+            p[2 + d] = o;
+            if (d == 0) {
+                p[0] = M;
+                p[1] = L;
+            }
+        }
+    }
+    (void)batch;
+}
+
+// merge the per-split partials: grid (head_num, batch), block = 64..256 threads over hs
+template <typename T>
+__global__ __launch_bounds__(256) void decode_attn_combine_kernel(const float *__restrict__ part,
+                                                                  T *__restrict__ out, int head_num,
+                                                                  int head_size, int chunk, int step_arg,
+                                                                  const int32_t *__restrict__ step_dev,
+                                                                  int max_splits) {
+    const int step = step_dev ? *step_dev : step_arg;
+    const int nsplits = (step + chunk - 1) / chunk;
+    if (nsplits <= 1) return;  // the split kernel already wrote the final output
+    const int h = blockIdx.x, b = blockIdx.y;
+    const float *p = part + (static_cast<size_t>(b) * head_num + h) * max_splits * (head_size + 2);
+    float M = -INFINITY;
+    for (int s = 0; s < nsplits; ++s) M = fmaxf(M, p[static_cast<size_t>(s) * (head_size + 2)]);
+    for (int d = threadIdx.x; d < head_size; d += blockDim.x) {
+        float L = 0.f, o = 0.f;
+        for (int s = 0; s < nsplits; ++s) {
+            const float *ps = p + static_cast<size_t>(s) * (head_size + 2);
+            const float f = __expf(ps[0] - M);
+            L += f * ps[1];
+            o += f * ps[2 + d];
+        }
+        out[(static_cast<size_t>(b) * head_num + h) * head_size + d] = from_f32<T>(o / (L + 1e-6f));
+    }
+}
+
+// Any head size / GQA ratio (e.g. the reference unit test's hs=4): one workgroup per (b, q-head),
+// scalar loads, logits in LDS.  step*4 bytes of dynamic LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void decode_attn_generic_kernel(
+    const T *__restrict__ qkv, const T *__restrict__ qkv_bias, T *k_cache, T *v_cache, T *__restrict__ out,
+    int head_num, int kv_head_num, int head_size, int max_seq_len, int step_arg,
+    const int32_t *__restrict__ step_dev) {
+    extern __shared__ float logits[];  // [step]
+    __shared__ float red[4];
+    const int step = step_dev ? *step_dev : step_arg;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int rep = head_num / kv_head_num, g = h / rep;
+    const int qkv_heads = head_num + 2 * kv_head_num;
+    const T *row = qkv + static_cast<size_t>(b) * qkv_heads * head_size;
+    const int hk = head_num + g, hv = head_num + kv_head_num + g;
+    const size_t head_off = (static_cast<size_t>(b) * kv_head_num + g) * max_seq_len * head_size;
+    T *kc = k_cache + head_off, *vc = v_cache + head_off;
+    const int t_new = step - 1;
+    const float scale = rsqrtf(static_cast<float>(head_size));
+    auto qv = [&](int d) { return to_f32(row[static_cast<size_t>(h) * head_size + d]) + (qkv_bias ? to_f32(qkv_bias[static_cast<size_t>(h) * head_size + d]) : 0.f); };
+    auto knew = [&](int d) { return from_f32<T>(to_f32(row[static_cast<size_t>(hk) * head_size + d]) + (qkv_bias ? to_f32(qkv_bias[static_cast<size_t>(hk) * head_size + d]) : 0.f)); };
+    auto vnew = [&](int d) { return from_f32<T>(to_f32(row[static_cast<size_t>(hv) * head_size + d]) + (qkv_bias ? to_f32(qkv_bias[static_cast<size_t>(hv) * head_size + d]) : 0.f)); };
+    if (h % rep == 0) {  // one q-head per kv group appends; the others read k/v_new from qkv
+        for (int d = threadIdx.x; d < head_size; d += 256) {
+            kc[static_cast<size_t>(t_new) * head_size + d] = knew(d);
+            vc[static_cast<size_t>(t_new) * head_size + d] = vnew(d);
+        }
+    }
+    float mx = -INFINITY;
+    for (int t = threadIdx.x; t < step; t += 256) {
+        float acc = 0.f;
+        for (int d = 0; d < head_size; ++d) {
+            const float kvl = (t == t_new) ? to_f32(knew(d)) : to_f32(kc[static_cast<size_t>(t) * head_size + d]);
+            acc = fmaf(qv(d), kvl, acc);
+        }
+        acc *= scale;
+        logits[t] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    mx = block_max<4>(mx, red);
+    float sum = 0.f;
+    for (int t = threadIdx.x; t < step; t += 256) {
+        const float p = expf(logits[t] - mx);
+        logits[t] = p;
+        sum += p;
+    }
+    sum = block_sum<4>(sum, red) + 1e-6f;
+    __syncthreads();
+    for (int d = threadIdx.x; d < head_size; d += 256) {
+        float o = 0.f;
+        for (int t = 0; t < step; ++t) {
+            const float vvl = (t == t_new) ? to_f32(vnew(d)) : to_f32(vc[static_cast<size_t>(t) * head_size + d]);
+            o = fmaf(logits[t], vvl, o);
+        }
+        out[(static_cast<size_t>(b) * head_num + h) * head_size + d] = from_f32<T>(o / sum);
+    }
+}
+
+template <typename T, int HS, int REP>
+static void launch_split(const T *qkv, const T *bias, T *kc, T *vc, float *part, T *out, int batch,
+                         int head_num, int kv_head_num, int max_seq_len, int step, const int32_t *step_dev,
+                         int max_splits_ws, hipStream_t st) {
+    constexpr int CHUNK = AttnGeom<T, HS>::CHUNK;
+    const int bound = step_dev ? max_seq_len : step;
+    const int splits = (bound + CHUNK - 1) / CHUNK;
+    dim3 grid(splits, kv_head_num, batch);
+    decode_attn_split_kernel<T, HS, REP><<<grid, 256, 0, st>>>(qkv, bias, kc, vc, part, out, head_num,
+                                                               kv_head_num, max_seq_len, step, step_dev, max_splits_ws);
+    if (splits > 1) {
+        dim3 cgrid(head_num, batch);
+        decode_attn_combine_kernel<T><<<cgrid, HS < 64 ? 64 : (HS > 256 ? 256 : HS), 0, st>>>(
+            part, out, head_num, HS, CHUNK, step, step_dev, max_splits_ws);
+    }
+}
+
+template <typename T, int HS>
+static bool dispatch_rep(int rep, const T *qkv, const T *bias, T *kc, T *vc, float *part, T *out, int batch,
+                         int head_num, int kv_head_num, int max_seq_len, int step, const int32_t *step_dev,
+                         int max_splits_ws, hipStream_t st) {
+    switch (rep) {
+        case 1: launch_split<T, HS, 1>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, st); return true;
+        case 2: launch_split<T, HS, 2>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, st); return true;
+        case 4: launch_split<T, HS, 4>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, st); return true;
+        case 8: launch_split<T, HS, 8>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, st); return true;
+        default: return false;
+    }
+}
+
+template <typename T>
+static int decoder_mha_impl(const T *qkv, const T *bias, T *k_cache, T *v_cache, T *out, int layer, int batch,
+                            int head_num, int kv_head_num, int head_size, int max_seq_len, int step,
+                            const int32_t *step_dev, void *workspace, size_t workspace_bytes, hipStream_t st) {
+    const size_t layer_off = static_cast<size_t>(layer) * batch * kv_head_num * max_seq_len * head_size;
+    T *kc = k_cache + layer_off, *vc = v_cache + layer_off;
+    const int rep = head_num / kv_head_num;
+    const int max_splits_ws = (max_seq_len + attn_min_chunk() - 1) / attn_min_chunk();
+    const bool aligned = ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(kc) |
+                           reinterpret_cast<uintptr_t>(vc)) % 16 == 0) && (!bias || reinterpret_cast<uintptr_t>(bias) % 16 == 0);
+    bool done = false;
+    if (aligned && batch <= 65535 && kv_head_num <= 65535) {
+        const size_t need = llmie_decoder_mha_workspace_bytes(batch, head_num, head_size, max_seq_len);
+        float *part = static_cast<float *>(workspace);
+        auto ws_ok = [&]() { return workspace && workspace_bytes >= need; };
+        if (head_size == 128 && ws_ok())
+            done = dispatch_rep<T, 128>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, st);
+        else if (head_size == 64 && ws_ok())
+            done = dispatch_rep<T, 64>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, st);
+        else if (head_size == 32 && ws_ok())
+            done = dispatch_rep<T, 32>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, st);
+        else if (head_size == 256 && ws_ok())
+            done = dispatch_rep<T, 256>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, st);
+        if (!done && (head_size == 128 || head_size == 64 || head_size == 32 || head_size == 256) && !ws_ok() &&
+            (rep == 1 || rep == 2 || rep == 4 || rep == 8)) {
+            set_error("decoder_mha: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
+            return LLMIE_ERR_WORKSPACE;
+        }
+    }
+    if (!done) {
+        const int bound = step_dev ? max_seq_len : step;
+        const size_t lds = sizeof(float) * static_cast<size_t>(bound);
+        if (lds > 60 * 1024) {
+            set_error("decoder_mha: generic path supports at most 15360 tokens (head_size=%d, rep=%d)", head_size, rep);
+            return LLMIE_ERR_UNSUPPORTED;
+        }
+        dim3 grid(head_num, batch);
+        decode_attn_generic_kernel<T><<<grid, 256, lds, st>>>(qkv, bias, kc, vc, out, head_num, kv_head_num,
+                                                             head_size, max_seq_len, step, step_dev);
+    }
+    return launch_status("decoder_mha");
+}
+
+}  // namespace llmie
+
+using namespace llmie;
+
+extern "C" size_t llmie_decoder_mha_workspace_bytes(int batch, int head_num, int head_size, int max_seq_len) {
+    if (batch <= 0 || head_num <= 0 || head_size <= 0 || max_seq_len <= 0) return 0;
+    const size_t splits = (static_cast<size_t>(max_seq_len) + attn_min_chunk() - 1) / attn_min_chunk();
+    return static_cast<size_t>(batch) * head_num * splits * (head_size + 2) * sizeof(float);
+}
+
+extern "C" int llmie_decoder_mha(const void *qkv, const void *qkv_bias, void *k_cache, void *v_cache, void *out,
+                                 int layer, int batch, int head_num, int kv_head_num, int head_size,
+                                 int max_seq_len, int step, const int32_t *step_dev, void *workspace,
+                                 size_t workspace_bytes, llmie_dtype dtype, llmie_stream stream) {
+    LLMIE_REQUIRE(qkv && k_cache && v_cache && out, "decoder_mha: NULL pointer");
+    LLMIE_REQUIRE(layer >= 0 && batch > 0 && head_num > 0 && kv_head_num > 0 && head_size > 0 && max_seq_len > 0,
+                  "decoder_mha: bad shape");
+    LLMIE_REQUIRE(head_num % kv_head_num == 0, "decoder_mha: kv_head_num must divide head_num");
+    LLMIE_REQUIRE(step_dev || (step >= 1 && step <= max_seq_len), "decoder_mha: step %d outside [1, max_seq_len=%d]",
+                  step, max_seq_len);
+    if (dtype == LLMIE_F32)
+        return decoder_mha_impl<float>((const float *)qkv, (const float *)qkv_bias, (float *)k_cache, (float *)v_cache,
+                                       (float *)out, layer, batch, head_num, kv_head_num, head_size, max_seq_len, step,
+                                       step_dev, workspace, workspace_bytes, as_stream(stream));
+    if (dtype == LLMIE_F16)
+        return decoder_mha_impl<half_t>((const half_t *)qkv, (const half_t *)qkv_bias, (half_t *)k_cache,
+                                        (half_t *)v_cache, (half_t *)out, layer, batch, head_num, kv_head_num, head_size,
+                                        max_seq_len, step, step_dev, workspace, workspace_bytes, as_stream(stream));
+    LLMIE_UNSUPPORTED("decoder_mha: dtype %d", (int)dtype);
+}

@@ -1,0 +1,90 @@
+// Device helpers: 64-lane wave reductions, 16-byte vector types, fp16<->fp32 packs.
+// Written for gfx950 (wave64, 4 SIMD-32 per CU); no 32-lane assumptions anywhere.
+#pragma once
+#include "llmie_common.h"
+
+namespace llmie {
+
+using half_t = _Float16;
+typedef half_t half2_t __attribute__((ext_vector_type(2)));
+typedef half_t half4_t __attribute__((ext_vector_type(4)));
+typedef half_t half8_t __attribute__((ext_vector_type(8)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef int int4_t __attribute__((ext_vector_type(4)));
+
+// element traits: 16-byte vector of T
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    using type = float4_t;
+    static constexpr int n = 4;
+};
+template <> struct Vec16<half_t> {
+    using type = half8_t;
+    static constexpr int n = 8;
+};
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return static_cast<float>(v); }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return static_cast<T>(v); }
+
+// ---- wave64 reductions (butterfly over 64 lanes) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// reduce within groups of `width` consecutive lanes (width power of two <= 64)
+template <int WIDTH> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block-wide sum for blocks of NW waves; `lds` needs NW floats. All threads get the result.
+template <int NW> __device__ __forceinline__ float block_sum(float v, float *lds) {
+    v = wave_sum(v);
+    if constexpr (NW == 1) return v;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();  // protect lds reuse across consecutive calls
+    if (lane == 0) lds[wid] = v;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r += lds[i];
+    return r;
+}
+template <int NW> __device__ __forceinline__ float block_max(float v, float *lds) {
+    v = wave_max(v);
+    if constexpr (NW == 1) return v;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) lds[wid] = v;
+    __syncthreads();
+    float r = lds[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) r = fmaxf(r, lds[i]);
+    return r;
+}
+
+// streaming (read-once) 16-byte load: non-temporal so weight streams do not evict reused lines
+template <typename V> __device__ __forceinline__ V load_nt(const V *p) {
+    return __builtin_nontemporal_load(p);
+}
+
+// dot of 8 halves with fp32 accumulate on v_dot2_f32_f16
+__device__ __forceinline__ float dot8(half8_t a, half8_t b, float acc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        half2_t x = {a[2 * i], a[2 * i + 1]};
+        half2_t y = {b[2 * i], b[2 * i + 1]};
+        acc = __builtin_amdgcn_fdot2(x, y, acc, false);
+    }
+    return acc;
+}
+
+}  // namespace llmie

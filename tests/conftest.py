@@ -9,6 +9,24 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
+def load_llmie():
+    """import llm-inference-engine_amd/ (hyphenated directory) as module `llmie_amd`"""
+    import importlib.util
+    if "llmie_amd" in sys.modules:
+        return sys.modules["llmie_amd"]
+    spec = importlib.util.spec_from_file_location(
+        "llmie_amd", os.path.join(ROOT, "llm-inference-engine_amd", "__init__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["llmie_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="session")
+def llmie():
+    return load_llmie()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -1,0 +1,68 @@
+"""CPU-side checks of the C-ABI boundary: the library builds/loads, exports every symbol that
+include/llmie.h declares, and rejects bad arguments before touching the GPU (no compute here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib(llmie):
+    llmie.build()
+    return llmie.lib()
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "llmie.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(llmie_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported(lib, llmie):
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), "libllmie.so does not export %s" % n
+    # and the python signature table covers the header exactly
+    assert sorted(llmie.EXPORTS) == names
+
+
+def test_version_and_arch(lib):
+    assert lib.llmie_abi_version() == 1
+    assert lib.llmie_target_arch() == b"gfx950"
+
+
+def test_code_object_is_gfx950(llmie):
+    data = open(llmie.LIB_PATH, "rb").read()
+    assert b"gfx950" in data
+    for other in (b"gfx942", b"gfx90a", b"sm_86"):
+        assert other not in data
+
+
+def test_invalid_arguments_fail_loudly(lib):
+    # NULL pointers / bad shapes are rejected on the host with a message (reference: LLM_CHECK throws)
+    assert lib.llmie_rmsnorm(None, None, None, 1e-6, 4, 8, 0, None) == -1
+    assert b"rmsnorm" in lib.llmie_last_error()
+    assert lib.llmie_linear(None, None, None, 1, 1, 1, 1, None, None, 1, None) == -1
+    assert lib.llmie_add_residual(None, None, 0, 0, 0, None) == -1
+    one = C.c_void_p(16)  # never dereferenced: shape check fails first
+    assert lib.llmie_topk(one, one, one, one, one, 1, 100, 64, 8, 0, None) == -1
+    assert b"K=64" in lib.llmie_last_error()
+    assert lib.llmie_decoder_mha(one, None, one, one, one, 0, 1, 3, 2, 8, 16, 1, None, None, 0, 0, None) == -1
+    assert b"kv_head_num" in lib.llmie_last_error()
+    assert lib.llmie_rmsnorm(one, None, one, 1e-6, 4, 8, 7, None) == -2  # unknown dtype
+
+
+def test_workspace_queries(lib):
+    assert lib.llmie_decoder_mha_workspace_bytes(1, 32, 128, 2048) == 1 * 32 * 64 * 130 * 4
+    assert lib.llmie_decoder_mha_workspace_bytes(0, 32, 128, 2048) == 0
+
+
+def test_missing_library_raises(llmie, monkeypatch):
+    monkeypatch.setattr(llmie, "_lib", None)
+    monkeypatch.setattr(llmie, "LIB_PATH", "/nonexistent/libllmie.so")
+    with pytest.raises(llmie.LlmieError):
+        llmie.lib()
