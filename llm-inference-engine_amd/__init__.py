@@ -254,3 +254,77 @@ def sampling(topk_id, topk_val, seq_len, finished, out_id, step, end_id, vocab, 
 
 def advance_step(step_dev):
     _check(lib().llmie_advance_step(_p(step_dev), _st()), "advance_step")
+
+
+# ------------------------------------------------------------------ fused decoder engine
+class Matrix(C.Structure):
+    _fields_ = [("data", _vp), ("scale", _vp), ("bias", _vp)]
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [("attn_norm_gamma", _vp), ("qkv", Matrix), ("o", Matrix), ("ffn_norm_gamma", _vp),
+                ("gate_up", Matrix), ("down", Matrix)]
+
+
+class DecoderConfig(C.Structure):
+    _fields_ = [("head_num", _i), ("kv_head_num", _i), ("head_size", _i), ("inter_size", _i), ("num_layers", _i),
+                ("vocab_size", _i), ("max_seq_len", _i), ("max_batch", _i), ("rotary_dim", _i),
+                ("rotary_base", _f), ("rms_eps", _f), ("dtype", _i), ("wfmt", _i), ("int4_group", _i)]
+
+
+def _mat(m):
+    """m: tensor | (data, scale) | (data, scale, bias) | dict"""
+    if isinstance(m, dict):
+        return Matrix(_p(m["data"]), _p(m.get("scale")), _p(m.get("bias")))
+    if isinstance(m, (tuple, list)):
+        m = list(m) + [None] * (3 - len(m))
+        return Matrix(_p(m[0]), _p(m[1]), _p(m[2]))
+    return Matrix(_p(m), None, None)
+
+
+class Decoder:
+    """Thin owner of an llmie_decoder handle + its workspace (torch only allocates the bytes).
+
+    layers: list of dicts with keys attn_norm, qkv, o, ffn_norm, gate_up, down; matrix entries are a
+    tensor (fp16/fp32 [N,K]) or dict(data=, scale=, bias=).
+    """
+
+    def __init__(self, cfg, layers):
+        import torch
+        self.cfg = DecoderConfig(**cfg)
+        self._keep = layers  # keep the weight tensors alive
+        arr = (LayerWeights * len(layers))()
+        for i, lw in enumerate(layers):
+            arr[i] = LayerWeights(_p(lw["attn_norm"]), _mat(lw["qkv"]), _mat(lw["o"]), _p(lw["ffn_norm"]),
+                                  _mat(lw["gate_up"]), _mat(lw["down"]))
+        nbytes = lib().llmie_decoder_workspace_bytes(C.byref(self.cfg))
+        if nbytes == 0:
+            raise LlmieError("invalid decoder config")
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        self.handle = lib().llmie_decoder_create(C.byref(self.cfg), arr, self.workspace.data_ptr(), nbytes)
+        if not self.handle:
+            raise LlmieError("decoder_create: " + lib().llmie_last_error().decode())
+
+    def forward(self, hidden_in, hidden_out, k_cache, v_cache, step, step_dev=None):
+        _check(lib().llmie_decoder_forward(self.handle, _p(hidden_in), _p(hidden_out), _p(k_cache), _p(v_cache),
+                                           hidden_in.shape[0], step, _p(step_dev), _st()), "decoder_forward")
+        return hidden_out
+
+    def lm_head_sample(self, hidden, final_gamma, lm_head, lm_fmt, logits, tmp_ids, tmp_vals, topk_ids, topk_vals,
+                       seq_len, finished, out_ids, step, end_id, blocks_per_row=8, step_dev=None):
+        m = _mat(lm_head)
+        _check(lib().llmie_lm_head_sample(self.handle, _p(hidden), _p(final_gamma), C.byref(m), lm_fmt, _p(logits),
+                                          _p(tmp_ids), _p(tmp_vals), _p(topk_ids), _p(topk_vals),
+                                          topk_ids.shape[-1], blocks_per_row, _p(seq_len), _p(finished), _p(out_ids),
+                                          hidden.shape[0], step, _p(step_dev), end_id, _st()), "lm_head_sample")
+
+    def close(self):
+        if self.handle:
+            lib().llmie_decoder_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

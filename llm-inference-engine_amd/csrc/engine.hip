@@ -1,0 +1,242 @@
+// Fused decoder engine: llmie_decoder_* and llmie_lm_head_sample.
+// This is what LlamaSelfDecoder<T>::forward (self_decoder.cpp:24-122) and
+// LlamaModel<T>::generateNextToken / LMHeadAndTopKSample (llama.cpp:219-318) run on.
+//
+// Differences from the reference's control flow, none of them numerical beyond rounding:
+//   * zero allocation / zero synchronisation per token: all scratch lives in one caller-owned
+//     workspace carved at create time (the reference mallocs+frees 5 buffers and syncs the
+//     device ~10x per layer, self_attention.cpp:29-45,150);
+//   * the position can live in device memory (step_dev) so the whole token step can be captured
+//     once in a hipGraph and replayed;
+//   * SwiGLU is the epilogue of the gate/up GEMV and the second residual add is the epilogue of
+//     the down GEMV (reference: launchSiluAndMul / launchAddResidual as separate kernels).
+#include "llmie_internal.h"
+
+#include <new>
+#include <vector>
+
+using namespace llmie;
+
+struct llmie_decoder {
+    llmie_decoder_config cfg;
+    std::vector<llmie_layer_weights> layers;
+    int H, QKV, I;
+    size_t esz;
+    // workspace carve-up
+    char *resid, *qkv, *mha, *normed, *act, *gu;
+    void *attn_ws;
+    size_t attn_ws_bytes;
+};
+
+static size_t align_up(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
+
+static bool config_ok(const llmie_decoder_config *c) {
+    if (!c) return false;
+    if (c->head_num <= 0 || c->kv_head_num <= 0 || c->head_size <= 0 || c->inter_size <= 0 ||
+        c->num_layers <= 0 || c->max_seq_len <= 0 || c->max_batch <= 0)
+        return false;
+    if (c->head_num % c->kv_head_num) return false;
+    if (c->rotary_dim <= 0 || c->rotary_dim % 2) return false;
+    if (c->dtype != LLMIE_F32 && c->dtype != LLMIE_F16) return false;
+    if (c->dtype == LLMIE_F32 && c->wfmt != LLMIE_W_F32) return false;
+    if (c->dtype == LLMIE_F16 && c->wfmt == LLMIE_W_F32) return false;
+    return true;
+}
+
+struct Carve {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        const size_t o = off;
+        off += align_up(bytes);
+        return o;
+    }
+};
+
+static size_t carve(const llmie_decoder_config *c, size_t *offs /*[7]*/) {
+    const size_t e = c->dtype == LLMIE_F16 ? 2 : 4;
+    const size_t B = c->max_batch, H = static_cast<size_t>(c->head_num) * c->head_size;
+    const size_t QKV = static_cast<size_t>(c->head_num + 2 * c->kv_head_num) * c->head_size;
+    const size_t I = c->inter_size;
+    Carve k;
+    offs[0] = k.take(B * H * e);        // resid
+    offs[1] = k.take(B * QKV * e);      // qkv
+    offs[2] = k.take(B * H * e);        // mha
+    offs[3] = k.take(B * H * e);        // normed / attn_out
+    offs[4] = k.take(B * I * e);        // act
+    offs[5] = k.take(B * 2 * I * e);    // gate_up (unfused paths)
+    offs[6] = k.take(llmie_decoder_mha_workspace_bytes(c->max_batch, c->head_num, c->head_size, c->max_seq_len));
+    return k.off;
+}
+
+extern "C" size_t llmie_decoder_workspace_bytes(const llmie_decoder_config *cfg) {
+    if (!config_ok(cfg)) return 0;
+    size_t offs[7];
+    return carve(cfg, offs);
+}
+
+extern "C" llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg, const llmie_layer_weights *layers,
+                                               void *workspace, size_t workspace_bytes) {
+    if (!config_ok(cfg)) {
+        set_error("decoder_create: invalid config");
+        return nullptr;
+    }
+    if (!layers || !workspace) {
+        set_error("decoder_create: NULL layers/workspace");
+        return nullptr;
+    }
+    size_t offs[7];
+    const size_t need = carve(cfg, offs);
+    if (workspace_bytes < need) {
+        set_error("decoder_create: workspace too small (%zu < %zu)", workspace_bytes, need);
+        return nullptr;
+    }
+    if (reinterpret_cast<uintptr_t>(workspace) % 256) {
+        set_error("decoder_create: workspace must be 256-byte aligned");
+        return nullptr;
+    }
+    for (int l = 0; l < cfg->num_layers; ++l) {
+        const llmie_layer_weights &w = layers[l];
+        if (!w.attn_norm_gamma || !w.ffn_norm_gamma || !w.qkv.data || !w.o.data || !w.gate_up.data || !w.down.data) {
+            set_error("decoder_create: layer %d has a NULL weight", l);
+            return nullptr;
+        }
+        if (cfg->wfmt != LLMIE_W_F16 && cfg->wfmt != LLMIE_W_F32 &&
+            (!w.qkv.scale || !w.o.scale || !w.gate_up.scale || !w.down.scale)) {
+            set_error("decoder_create: layer %d lacks quantisation scales", l);
+            return nullptr;
+        }
+    }
+    llmie_decoder *d = new (std::nothrow) llmie_decoder();
+    if (!d) return nullptr;
+    d->cfg = *cfg;
+    d->layers.assign(layers, layers + cfg->num_layers);
+    d->H = cfg->head_num * cfg->head_size;
+    d->QKV = (cfg->head_num + 2 * cfg->kv_head_num) * cfg->head_size;
+    d->I = cfg->inter_size;
+    d->esz = cfg->dtype == LLMIE_F16 ? 2 : 4;
+    char *base = static_cast<char *>(workspace);
+    d->resid = base + offs[0];
+    d->qkv = base + offs[1];
+    d->mha = base + offs[2];
+    d->normed = base + offs[3];
+    d->act = base + offs[4];
+    d->gu = base + offs[5];
+    d->attn_ws = base + offs[6];
+    d->attn_ws_bytes = llmie_decoder_mha_workspace_bytes(cfg->max_batch, cfg->head_num, cfg->head_size, cfg->max_seq_len);
+    return d;
+}
+
+extern "C" void llmie_decoder_destroy(llmie_decoder *dec) { delete dec; }
+
+// y = x . W^T (+bias)(+residual) | swiglu, dispatching on the engine's weight format
+static int engine_linear(const llmie_decoder *d, llmie_weight_format fmt, const void *x, const llmie_matrix &w,
+                         void *y, int M, int K, int N, bool swiglu, const void *residual, bool use_bias,
+                         llmie_stream stream) {
+    const void *bias = use_bias ? w.bias : nullptr;
+    switch (fmt) {
+        case LLMIE_W_F16:
+            return linear_f16_nk((const half_t *)x, (const half_t *)w.data, (half_t *)y, M, K, N,
+                                 swiglu ? EPI_SWIGLU_ : EPI_NONE_, (const half_t *)bias, (const half_t *)residual,
+                                 as_stream(stream));
+        case LLMIE_W_F32:
+            if (swiglu) {
+                int rc = llmie_linear(x, w.data, d->gu, M, K, N, 1, bias, nullptr, LLMIE_F32, stream);
+                if (rc) return rc;
+                return llmie_silu_and_mul(d->gu, y, M, N / 2, LLMIE_F32, stream);
+            }
+            return llmie_linear(x, w.data, y, M, K, N, 1, bias, residual, LLMIE_F32, stream);
+        case LLMIE_W_INT8:
+            if (swiglu) {
+                int rc = llmie_linear_w8a16(x, (const int8_t *)w.data, w.scale, d->gu, M, K, N, bias, nullptr, stream);
+                if (rc) return rc;
+                return llmie_silu_and_mul(d->gu, y, M, N / 2, LLMIE_F16, stream);
+            }
+            return llmie_linear_w8a16(x, (const int8_t *)w.data, w.scale, y, M, K, N, bias, residual, stream);
+        case LLMIE_W_INT4:
+            if (swiglu) {
+                int rc = llmie_linear_w4a16(x, (const uint8_t *)w.data, w.scale, d->gu, M, K, N, d->cfg.int4_group, bias,
+                                            nullptr, stream);
+                if (rc) return rc;
+                return llmie_silu_and_mul(d->gu, y, M, N / 2, LLMIE_F16, stream);
+            }
+            return llmie_linear_w4a16(x, (const uint8_t *)w.data, w.scale, y, M, K, N, d->cfg.int4_group, bias, residual,
+                                      stream);
+        default:
+            set_error("engine: weight format %d not supported by this build", (int)fmt);
+            return LLMIE_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, void *hidden_out, void *k_cache,
+                                     void *v_cache, int batch, int step, const int32_t *step_dev,
+                                     llmie_stream stream) {
+    LLMIE_REQUIRE(dec && hidden_in && hidden_out && k_cache && v_cache, "decoder_forward: NULL pointer");
+    const llmie_decoder_config &c = dec->cfg;
+    LLMIE_REQUIRE(batch >= 1 && batch <= c.max_batch, "decoder_forward: batch %d outside [1,%d]", batch, c.max_batch);
+    LLMIE_REQUIRE(step_dev || (step >= 1 && step <= c.max_seq_len), "decoder_forward: step %d outside [1,%d]", step,
+                  c.max_seq_len);
+    const int H = dec->H, QKV = dec->QKV, I = dec->I;
+    const llmie_dtype dt = c.dtype;
+    int rc;
+    if (hidden_out != hidden_in) {
+        hipError_t e = hipMemcpyAsync(hidden_out, hidden_in, static_cast<size_t>(batch) * H * dec->esz,
+                                      hipMemcpyDeviceToDevice, as_stream(stream));
+        if (e != hipSuccess) {
+            set_error("decoder_forward: copy failed: %s", hipGetErrorString(e));
+            return LLMIE_ERR_LAUNCH;
+        }
+    }
+    void *h = hidden_out;  // running hidden state, updated in place like decoder_output in the reference
+    for (int l = 0; l < c.num_layers; ++l) {
+        const llmie_layer_weights &w = dec->layers[l];
+        // self_decoder.cpp:77  resid = h ; h = rmsnorm(h)
+        if ((rc = llmie_rmsnorm(h, dec->resid, w.attn_norm_gamma, c.rms_eps, batch, H, dt, stream))) return rc;
+        // self_attention.cpp:79  qkv = h . Wqkv^T   (bias is applied inside the MHA kernel, as the reference)
+        if ((rc = engine_linear(dec, c.wfmt, h, w.qkv, dec->qkv, batch, H, QKV, false, nullptr, false, stream))) return rc;
+        // :100 RoPE at position step-1
+        if ((rc = llmie_rope_decode(dec->qkv, batch, c.head_num, c.kv_head_num, c.head_size, step, step_dev,
+                                    c.rotary_dim, c.rotary_base, dt, stream)))
+            return rc;
+        // :108 fused masked MHA with KV append
+        if ((rc = llmie_decoder_mha(dec->qkv, w.qkv.bias, k_cache, v_cache, dec->mha, l, batch, c.head_num,
+                                    c.kv_head_num, c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws,
+                                    dec->attn_ws_bytes, dt, stream)))
+            return rc;
+        // :131 output projection (no bias here: the fused norm below adds o.bias, self_decoder.cpp:92-98)
+        if ((rc = engine_linear(dec, c.wfmt, dec->mha, w.o, h, batch, H, H, false, nullptr, false, stream))) return rc;
+        // self_decoder.cpp:92  h += resid; resid = h; h += o.bias; h = rmsnorm(h, ffn_gamma)
+        if ((rc = llmie_fused_add_bias_residual_rmsnorm(dec->resid, h, w.o.bias, w.ffn_norm_gamma, c.rms_eps, batch, H,
+                                                        dt, stream)))
+            return rc;
+        // ffn.cpp:105-122  act = silu(h.Wg^T) * (h.Wu^T)
+        if ((rc = engine_linear(dec, c.wfmt, h, w.gate_up, dec->act, batch, H, 2 * I, true, nullptr, false, stream))) return rc;
+        // ffn.cpp:132 + self_decoder.cpp:111  h = act . Wd^T + resid
+        if ((rc = engine_linear(dec, c.wfmt, dec->act, w.down, h, batch, I, H, false, dec->resid, false, stream))) return rc;
+    }
+    return LLMIE_OK;
+}
+
+extern "C" int llmie_lm_head_sample(llmie_decoder *dec, void *hidden, const void *final_norm_gamma,
+                                    const llmie_matrix *lm_head, llmie_weight_format lm_fmt, void *logits,
+                                    int32_t *tmp_ids, void *tmp_vals, int32_t *topk_ids, void *topk_vals, int K,
+                                    int blocks_per_row, int32_t *seq_len, uint8_t *finished, int32_t *out_ids,
+                                    int batch, int step, const int32_t *step_dev, int end_id, llmie_stream stream) {
+    LLMIE_REQUIRE(dec && hidden && final_norm_gamma && lm_head && lm_head->data && logits && topk_ids && topk_vals &&
+                      seq_len && finished && out_ids, "lm_head_sample: NULL pointer");
+    const llmie_decoder_config &c = dec->cfg;
+    LLMIE_REQUIRE(batch >= 1 && batch <= c.max_batch, "lm_head_sample: batch %d outside [1,%d]", batch, c.max_batch);
+    LLMIE_REQUIRE(c.vocab_size > 0, "lm_head_sample: vocab_size not set in the decoder config");
+    int rc;
+    // llama.cpp:247  final RMSNorm (the residual copy is unused there: pass NULL)
+    if ((rc = llmie_rmsnorm(hidden, nullptr, final_norm_gamma, c.rms_eps, batch, dec->H, c.dtype, stream))) return rc;
+    // llama.cpp:282  logits = hidden . lm_head^T
+    if ((rc = engine_linear(dec, lm_fmt, hidden, *lm_head, logits, batch, dec->H, c.vocab_size, false, nullptr, false,
+                            stream)))
+        return rc;
+    // llama.cpp:293,304
+    if ((rc = llmie_topk(logits, tmp_ids, tmp_vals, topk_ids, topk_vals, batch, c.vocab_size, K, blocks_per_row, c.dtype,
+                         stream)))
+        return rc;
+    return llmie_sampling(topk_ids, topk_vals, seq_len, finished, out_ids, batch, K, step, step_dev, end_id,
+                          c.vocab_size, c.dtype, stream);
+}

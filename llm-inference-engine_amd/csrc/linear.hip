@@ -1,5 +1,6 @@
 // llmie_linear / llmie_batched_gemm: shape dispatch over the kernels in gemm_kernels.cuh.
 #include "gemm_kernels.cuh"
+#include "llmie_internal.h"
 
 #include <cstdlib>
 
