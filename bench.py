@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""bench.py -- decode throughput of the MI355X-native Llama-2-7B hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on; fits one GPU):
+Llama-2-7B, 32 layers, fp16 weights/activations/KV, batch 1, context 2048 (the K timed steps
+are the last K positions of a 2048-token context, KV pre-filled), random-init weights,
+synthetic token ids.  One "step" = one generated token: embedding -> 32 decoder layers ->
+final RMSNorm -> LM head -> top-k -> sampling -> token id to pinned host memory, all through
+the C ABI (include/llmie.h), captured once in a hipGraph and replayed.
+
+N > 1 = N independent data-parallel replicas (one process per GPU, no collective on the data
+path; torch.distributed/gloo only for the start/stop barrier and the MAX over ranks).
+
+Prints ONE JSON line (rank 0).  Extra keys beside the driver contract:
+  roofline      dominant kernel (gate/up GEMV + SwiGLU): algorithmic bytes per launch / mean launch
+                duration measured with hipEvents on the launch stream (engine profiling pass, eager
+                launches of the same step right after the timed region).
+  cpu_baseline  the oracle (CPU restatement of the reference kernels, oracle/) timed on this host
+                on a bounded sample (1 of 32 layers x32 + LM head), rank 0 / N=1 only.
+  breakdown     per-op device time of one step from the same profiling pass.
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 measured copy)
+
+LLAMA2_7B = dict(head_num=32, kv_head_num=32, head_size=128, inter_size=11008, num_layers=32, vocab_size=32000)
+
+
+def load_llmie():
+    spec = importlib.util.spec_from_file_location("llmie_amd", os.path.join(ROOT, "llm-inference-engine_amd", "__init__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["llmie_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def build_model(torch, llmie, cfg, batch, max_seq, seed):
+    """random-init Llama-2 weights of the named architecture, resident in HBM"""
+    dev = "cuda"
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    H = cfg["head_num"] * cfg["head_size"]
+    QKV = (cfg["head_num"] + 2 * cfg["kv_head_num"]) * cfg["head_size"]
+    I, L, V = cfg["inter_size"], cfg["num_layers"], cfg["vocab_size"]
+
+    def w(n, k):
+        # zero-mean U(-a, a) with std 1/sqrt(k): activations stay O(1) through 32 layers
+        a = (3.0 / k) ** 0.5
+        return ((torch.rand((n, k), generator=g, device=dev, dtype=torch.float32) * 2 - 1) * a).to(torch.float16)
+
+    layers = []
+    for _ in range(L):
+        layers.append(dict(attn_norm=torch.ones(H, dtype=torch.float16, device=dev),
+                           ffn_norm=torch.ones(H, dtype=torch.float16, device=dev),
+                           qkv=w(QKV, H), o=w(H, H), gate_up=w(2 * I, H), down=w(H, I)))
+    model = dict(layers=layers, embed=w(V, H), lm_head=w(V, H),
+                 final_norm=torch.ones(H, dtype=torch.float16, device=dev))
+    kv_shape = (L, batch, cfg["kv_head_num"], max_seq, cfg["head_size"])
+    model["k_cache"] = (torch.randn(kv_shape, generator=g, device=dev, dtype=torch.float32) * 0.5).to(torch.float16)
+    model["v_cache"] = (torch.randn(kv_shape, generator=g, device=dev, dtype=torch.float32) * 0.5).to(torch.float16)
+    ecfg = dict(cfg, max_seq_len=max_seq, max_batch=batch, rotary_dim=cfg["head_size"], rotary_base=10000.0,
+                rms_eps=1e-5, dtype=llmie.F16, wfmt=llmie.W_F16, int4_group=128)
+    model["decoder"] = llmie.Decoder(ecfg, layers)
+    return model
+
+
+def decode_bytes_per_step(cfg, batch, ctx):
+    """weights once per step + KV read + KV append (fp16 everywhere)"""
+    H = cfg["head_num"] * cfg["head_size"]
+    KVH = cfg["kv_head_num"] * cfg["head_size"]
+    I, L, V = cfg["inter_size"], cfg["num_layers"], cfg["vocab_size"]
+    weights = L * ((H + 2 * KVH) * H + H * H + 3 * H * I) * 2 + V * H * 2
+    kv = batch * L * 2 * ctx * KVH * 2 + batch * L * 2 * KVH * 2
+    return weights + kv
+
+
+def cpu_baseline(cfg, ctx, budget_s=25.0):
+    """Times the oracle's decode step on the host cores (bounded sample: one layer + LM head)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    rng = np.random.default_rng(0)
+    nh, kvh, hs, I, V = cfg["head_num"], cfg["kv_head_num"], cfg["head_size"], cfg["inter_size"], cfg["vocab_size"]
+    H, QKV = nh * hs, (nh + 2 * kvh) * hs
+
+    def w(n, k):
+        return rng.uniform(-1, 1, (n, k)).astype(np.float32) * np.float32((3.0 / k) ** 0.5)
+
+    layer = dict(attn_norm=np.ones(H, np.float32), qkv=w(QKV, H), qkv_bias=None, o=w(H, H), o_bias=None,
+                 ffn_norm=np.ones(H, np.float32), gate_up=w(2 * I, H), down=w(H, I))
+    lm = w(V, H)
+    kc = (rng.standard_normal((1, 1, kvh, ctx, hs)) * 0.5).astype(np.float32)
+    vc = (rng.standard_normal((1, 1, kvh, ctx, hs)) * 0.5).astype(np.float32)
+    ocfg = dict(head_num=nh, kv_head_num=kvh, head_size=hs, inter_size=I, num_layers=1, vocab=V, max_seq_len=ctx,
+                rotary_dim=hs, rotary_base=10000.0, rms_eps=1e-5)
+    x = rng.standard_normal((1, H)).astype(np.float32)
+    orc.self_decoder(ocfg, [layer], x, kc, vc, ctx)  # warm-up (page in)
+    t_layer, t_lm, reps = [], [], 0
+    t_begin = time.perf_counter()
+    while reps < 3 or (time.perf_counter() - t_begin < budget_s and reps < 12):
+        t0 = time.perf_counter()
+        h = orc.self_decoder(ocfg, [layer], x, kc, vc, ctx)
+        t1 = time.perf_counter()
+        hn, _ = orc.rmsnorm(h, np.ones(H, np.float32), 1e-5)
+        logits = orc.linear(hn, lm)
+        ids, vals = orc.topk(logits, 4)
+        orc.sampling(ids, vals, np.zeros(1, np.int32), np.zeros(1, np.uint8), ctx, 2, V)
+        t2 = time.perf_counter()
+        t_layer.append(t1 - t0)
+        t_lm.append(t2 - t1)
+        reps += 1
+    tl, tm = sorted(t_layer)[len(t_layer) // 2], sorted(t_lm)[len(t_lm) // 2]
+    step_s = cfg["num_layers"] * tl + tm
+    return dict(value=1.0 / step_s, unit="tokens/s", cores=int(orc.lib().orc_num_threads()), kind="port",
+                sample="oracle (fp32 C restatement of the reference kernels, OpenMP) decode step at ctx %d: "
+                       "1 of %d layers timed (median of %d runs: %.3f s) x%d + LM head/top-k/sampling (%.3f s)"
+                       % (ctx, cfg["num_layers"], reps, tl, cfg["num_layers"], tm))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--ctx", type=int, default=2048, help="context length the timed steps end at")
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--layers", type=int, default=0, help="DEBUG ONLY: fewer layers (result marked invalid)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    torch.cuda.set_device(local_rank if world > 1 else 0)
+    llmie = load_llmie()
+    llmie.lib()  # fail loudly if the HIP library is missing
+
+    cfg = dict(LLAMA2_7B)
+    if args.layers:
+        cfg["num_layers"] = args.layers
+    B, K, W, S = args.batch, args.steps, args.warmup, args.ctx
+    H, V = cfg["head_num"] * cfg["head_size"], cfg["vocab_size"]
+    model = build_model(torch, llmie, cfg, B, S, seed=1234 + rank)
+    dec = model["decoder"]
+    dev = "cuda"
+    TOPK, BPR = 4, 8
+    ids = torch.randint(0, V, (B,), dtype=torch.int32, device=dev)
+    hidden = torch.empty((B, H), dtype=torch.float16, device=dev)
+    logits = torch.empty((B, V), dtype=torch.float16, device=dev)
+    tmp_ids = torch.empty((B, BPR, TOPK), dtype=torch.int32, device=dev)
+    tmp_vals = torch.empty((B, BPR, TOPK), dtype=torch.float16, device=dev)
+    top_ids = torch.empty((B, TOPK), dtype=torch.int32, device=dev)
+    top_vals = torch.empty((B, TOPK), dtype=torch.float16, device=dev)
+    seq_len = torch.zeros(B, dtype=torch.int32, device=dev)
+    finished = torch.zeros(B, dtype=torch.uint8, device=dev)
+    host_tok = torch.empty(B, dtype=torch.int32, pin_memory=True)
+    total = K + W
+    start_step = max(1, S - total + 1)
+    step_dev = torch.tensor([start_step], dtype=torch.int32, device=dev)
+
+    def one_step():
+        llmie.input_embedding(ids, model["embed"], hidden)
+        dec.forward(hidden, hidden, model["k_cache"], model["v_cache"], -1, step_dev=step_dev)
+        dec.lm_head_sample(hidden, model["final_norm"], model["lm_head"], llmie.W_F16, logits, tmp_ids, tmp_vals,
+                           top_ids, top_vals, seq_len, finished, ids, step=-1, end_id=-1, blocks_per_row=BPR,
+                           step_dev=step_dev)
+        llmie.advance_step(step_dev)
+        host_tok.copy_(ids, non_blocking=True)
+
+    stream = torch.cuda.Stream()
+    graph = None
+    with torch.cuda.stream(stream):
+        one_step()  # eager once (also validates every launch)
+        step_dev.fill_(start_step)
+    stream.synchronize()
+    if not args.no_graph:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            one_step()
+        step_dev.fill_(start_step)
+    torch.cuda.synchronize()
+
+    host_step = [start_step]
+
+    def run(n):
+        with torch.cuda.stream(stream):
+            for _ in range(n):
+                if host_step[0] > S:  # context full: wrap (only when steps+warmup > ctx)
+                    step_dev.fill_(1)
+                    host_step[0] = 1
+                if graph is not None:
+                    graph.replay()
+                else:
+                    one_step()
+                host_step[0] += 1
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    run(W)
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    run(K)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    elapsed = t1 - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tokens = world * B * K
+    value = tokens / elapsed
+    ms_per_step = elapsed / K * 1e3
+
+    # ---- per-kernel timing with hipEvents on the launch stream (eager launches of the same step) ----
+    P = 4
+    with torch.cuda.stream(stream):
+        step_dev.fill_(max(1, S - P + 1))
+        one_step()  # untimed: re-warm after the fill
+        step_dev.fill_(max(1, S - P + 1))
+        dec.profile_begin(P * (cfg["num_layers"] * 8 + 4))
+        for _ in range(P):
+            one_step()
+        prof = dec.profile_end()
+    breakdown = {op: dict(us_per_launch=round(ms / n * 1e3, 2), launches_per_step=n // P,
+                          us_per_step=round(ms / P * 1e3, 1))
+                 for op, (ms, n) in prof.items() if n}
+    I = cfg["inter_size"]
+    gu_bytes = 2 * I * H * 2  # fused gate_up matrix streamed once per launch (180.4 MB)
+    gu_ms, gu_n = prof["gate_up_swiglu"]
+    gu_us = gu_ms / gu_n * 1e3
+    achieved = gu_bytes / (gu_us * 1e-6) / 1e9
+    roofline = dict(bound="hbm", kernel="gemv_f16_kernel<M=%d, SWIGLU> (gate/up projection + SwiGLU)" % B,
+                    achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    algorithmic_bytes_per_launch=gu_bytes, us_per_launch=round(gu_us, 2), launches_timed=gu_n)
+    step_bytes = decode_bytes_per_step(cfg, B, S)
+    whole = dict(algorithmic_bytes_per_step=step_bytes,
+                 achieved_GBs=round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                 frac_of_hbm_peak=round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+
+    out = {
+        "metric": "decode_tokens_per_s", "value": round(value, 2), "unit": "tokens/s", "n_gpus": world,
+        "steps": K, "warmup": W, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": "Llama-2-7B 32-layer fp16 decode, batch %d, ctx %d (BASELINE configs[2]); "
+                               "random-init weights, synthetic ids, KV pre-filled" % (B, S),
+                   "global_batch": world * B, "seq_len": S, "parallelism": "replicas x%d (no collective)" % world,
+                   "graph": graph is not None, "layers": cfg["num_layers"]},
+        "metric_full": "decode tokens/s + prefill tokens/s, Llama-2-7B fp16 & int8, 1 MI355X",
+        "roofline": roofline, "whole_step": whole, "breakdown": breakdown,
+    }
+    if args.layers:
+        out["config"]["INVALID_debug_layers"] = args.layers
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, S)
+    else:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    dec.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

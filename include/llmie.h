@@ -100,6 +100,12 @@ int llmie_linear(const void *x, const void *w, void *y, int M, int K, int N, int
                  const void *bias, const void *residual,
                  llmie_dtype dtype, llmie_stream stream);
 
+/* replaces launchLinearGemm(gate_and_up) + launchSiluAndMul   src/layers/ffn.cpp:105-122,
+ * src/kernels/silu_and_mul.cu:61-82 in one kernel: w is the fused gate_up matrix [2I,K]
+ * (rows [0,I) gate, [I,2I) up); y[M,I] = silu(x.Wg^T) * (x.Wu^T).  fp16 only (decode path). */
+int llmie_linear_swiglu(const void *x, const void *w, void *y, int M, int K, int two_inter,
+                        llmie_dtype dtype, llmie_stream stream);
+
 /* replaces launchLinearStridedBatchGemm src/kernels/linear.cu:89-158 (+ cublas_utils.cpp:95-154)
  * per batch i: C_i[m,n] = A_i[m,k] . B_i  (B_i is [n,k] if trans_b else [k,n]); dense strides */
 int llmie_batched_gemm(const void *a, const void *b, void *c, int batch, int m, int n, int k,
@@ -266,6 +272,19 @@ int llmie_lm_head_sample(llmie_decoder *dec, void *hidden /* [bs,H], normalised 
                          int K, int blocks_per_row, int32_t *seq_len, uint8_t *finished,
                          int32_t *out_ids, int batch, int step, const int32_t *step_dev,
                          int end_id, llmie_stream stream);
+
+/* Per-kernel timing of the engine (eager launches only, never inside graph capture): between
+ * profile_begin and profile_end every kernel the engine launches is bracketed by hipEvents
+ * recorded on the launch stream.  profile_end synchronises the stream (the one entry point that
+ * does) and returns, per op kind, the summed device time in ms and the number of launches. */
+enum {
+    LLMIE_OP_ATTN_NORM = 0, LLMIE_OP_QKV_GEMM, LLMIE_OP_ROPE, LLMIE_OP_MHA, LLMIE_OP_O_GEMM,
+    LLMIE_OP_FFN_NORM, LLMIE_OP_GATE_UP_SWIGLU, LLMIE_OP_DOWN_GEMM, LLMIE_OP_FINAL_NORM,
+    LLMIE_OP_LM_HEAD, LLMIE_OP_TOPK, LLMIE_OP_SAMPLING, LLMIE_OP_COUNT
+};
+int llmie_decoder_profile_begin(llmie_decoder *dec, int max_events);
+int llmie_decoder_profile_end(llmie_decoder *dec, llmie_stream stream, double *ms_by_op /*[LLMIE_OP_COUNT]*/,
+                              int *launches_by_op /*[LLMIE_OP_COUNT]*/);
 
 /* device-side helper for graph replay: *step_dev += 1 */
 int llmie_advance_step(int32_t *step_dev, llmie_stream stream);

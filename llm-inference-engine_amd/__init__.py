@@ -45,6 +45,7 @@ _SIGS = {
     "llmie_fused_add_bias_residual_rmsnorm": [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp],
     "llmie_add_residual": [_vp, _vp, _i, _i, _i, _vp],
     "llmie_linear": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],
+    "llmie_linear_swiglu": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "llmie_batched_gemm": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "llmie_qkv_bias_transpose_rope": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "llmie_rope_decode": [_vp, _i, _i, _i, _i, _i, _vp, _i, _f, _i, _vp],
@@ -71,6 +72,8 @@ _SIGS = {
     "llmie_lm_head_sample": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp,
                              _i, _vp],
     "llmie_advance_step": [_vp, _vp],
+    "llmie_decoder_profile_begin": [_vp, _i],
+    "llmie_decoder_profile_end": [_vp, _vp, _vp, _vp],
     "llmie_abi_version": [],
     "llmie_last_error": [],
     "llmie_target_arch": [],
@@ -96,6 +99,9 @@ def lib():
             raise LlmieError(
                 "HIP library %s is missing: run `python llm-inference-engine_amd/build.py` "
                 "(or __graft_entry__.build()).  There is no CPU fallback." % LIB_PATH)
+        # torch ships its own libamdhip64; load it FIRST so libllmie.so binds to the same HIP runtime
+        # (two runtimes in one process = "no ROCm-capable device" on the second one).
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, args in _SIGS.items():
             fn = getattr(l, name)  # AttributeError if the ABI lost a symbol
@@ -170,6 +176,12 @@ def linear(x, w, y, trans_b=True, bias=None, residual=None):
     N = y.numel() // y.shape[0]
     _check(lib().llmie_linear(_p(x), _p(w), _p(y), M, K, N, int(trans_b), _p(bias), _p(residual), _dt(x), _st()),
            "linear")
+    return y
+
+
+def linear_swiglu(x, w_gate_up, y):
+    _check(lib().llmie_linear_swiglu(_p(x), _p(w_gate_up), _p(y), x.shape[0], x.shape[1], w_gate_up.shape[0],
+                                     _dt(x), _st()), "linear_swiglu")
     return y
 
 
@@ -317,6 +329,19 @@ class Decoder:
                                           _p(tmp_ids), _p(tmp_vals), _p(topk_ids), _p(topk_vals),
                                           topk_ids.shape[-1], blocks_per_row, _p(seq_len), _p(finished), _p(out_ids),
                                           hidden.shape[0], step, _p(step_dev), end_id, _st()), "lm_head_sample")
+
+    OPS = ("attn_norm", "qkv_gemm", "rope", "mha", "o_gemm", "ffn_norm", "gate_up_swiglu", "down_gemm",
+           "final_norm", "lm_head", "topk", "sampling")
+
+    def profile_begin(self, max_events):
+        _check(lib().llmie_decoder_profile_begin(self.handle, max_events), "decoder_profile_begin")
+
+    def profile_end(self):
+        """-> {op: (total_ms, launches)}; synchronises the current stream"""
+        ms = (C.c_double * len(self.OPS))()
+        n = (C.c_int * len(self.OPS))()
+        _check(lib().llmie_decoder_profile_end(self.handle, _st(), ms, n), "decoder_profile_end")
+        return {op: (ms[i], n[i]) for i, op in enumerate(self.OPS)}
 
     def close(self):
         if self.handle:

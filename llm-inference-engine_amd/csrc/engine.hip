@@ -26,7 +26,36 @@ struct llmie_decoder {
     char *resid, *qkv, *mha, *normed, *act, *gu;
     void *attn_ws;
     size_t attn_ws_bytes;
+    // profiling (eager only)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;      // pairs: start, stop
+    std::vector<int> ev_op;          // op kind of pair i
+    size_t ev_used = 0;
 };
+
+// brackets one engine op with events when profiling
+struct OpTimer {
+    llmie_decoder *d;
+    hipStream_t st;
+    bool on;
+    size_t idx;
+    OpTimer(llmie_decoder *dec, int op, llmie_stream s) : d(dec), st(as_stream(s)), on(false), idx(0) {
+        if (d->profiling && d->ev_used + 1 <= d->ev_op.size()) {
+            idx = d->ev_used++;
+            d->ev_op[idx] = op;
+            on = hipEventRecord(d->ev[2 * idx], st) == hipSuccess;
+        }
+    }
+    ~OpTimer() {
+        if (on) (void)hipEventRecord(d->ev[2 * idx + 1], st);
+    }
+};
+#define TIMED(op, expr)                 \
+    do {                                \
+        OpTimer _t(dec, op, stream);    \
+        rc = (expr);                    \
+    } while (0);                        \
+    if (rc) return rc
 
 static size_t align_up(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
 
@@ -126,7 +155,49 @@ extern "C" llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg, 
     return d;
 }
 
-extern "C" void llmie_decoder_destroy(llmie_decoder *dec) { delete dec; }
+extern "C" void llmie_decoder_destroy(llmie_decoder *dec) {
+    if (!dec) return;
+    for (hipEvent_t e : dec->ev) (void)hipEventDestroy(e);
+    delete dec;
+}
+
+extern "C" int llmie_decoder_profile_begin(llmie_decoder *dec, int max_events) {
+    LLMIE_REQUIRE(dec && max_events > 0, "decoder_profile_begin: bad arguments");
+    while (dec->ev.size() < 2 * static_cast<size_t>(max_events)) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) {
+            set_error("decoder_profile_begin: hipEventCreate failed");
+            return LLMIE_ERR_LAUNCH;
+        }
+        dec->ev.push_back(e);
+    }
+    dec->ev_op.assign(max_events, 0);
+    dec->ev_used = 0;
+    dec->profiling = true;
+    return LLMIE_OK;
+}
+
+extern "C" int llmie_decoder_profile_end(llmie_decoder *dec, llmie_stream stream, double *ms_by_op, int *launches_by_op) {
+    LLMIE_REQUIRE(dec && ms_by_op && launches_by_op, "decoder_profile_end: NULL pointer");
+    dec->profiling = false;
+    if (hipStreamSynchronize(as_stream(stream)) != hipSuccess) {
+        set_error("decoder_profile_end: stream synchronise failed");
+        return LLMIE_ERR_LAUNCH;
+    }
+    for (int i = 0; i < LLMIE_OP_COUNT; ++i) {
+        ms_by_op[i] = 0.0;
+        launches_by_op[i] = 0;
+    }
+    for (size_t i = 0; i < dec->ev_used; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, dec->ev[2 * i], dec->ev[2 * i + 1]) == hipSuccess) {
+            ms_by_op[dec->ev_op[i]] += ms;
+            launches_by_op[dec->ev_op[i]] += 1;
+        }
+    }
+    dec->ev_used = 0;
+    return LLMIE_OK;
+}
 
 // y = x . W^T (+bias)(+residual) | swiglu, dispatching on the engine's weight format
 static int engine_linear(const llmie_decoder *d, llmie_weight_format fmt, const void *x, const llmie_matrix &w,
@@ -190,28 +261,25 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
     for (int l = 0; l < c.num_layers; ++l) {
         const llmie_layer_weights &w = dec->layers[l];
         // self_decoder.cpp:77  resid = h ; h = rmsnorm(h)
-        if ((rc = llmie_rmsnorm(h, dec->resid, w.attn_norm_gamma, c.rms_eps, batch, H, dt, stream))) return rc;
+        TIMED(LLMIE_OP_ATTN_NORM, llmie_rmsnorm(h, dec->resid, w.attn_norm_gamma, c.rms_eps, batch, H, dt, stream));
         // self_attention.cpp:79  qkv = h . Wqkv^T   (bias is applied inside the MHA kernel, as the reference)
-        if ((rc = engine_linear(dec, c.wfmt, h, w.qkv, dec->qkv, batch, H, QKV, false, nullptr, false, stream))) return rc;
+        TIMED(LLMIE_OP_QKV_GEMM, engine_linear(dec, c.wfmt, h, w.qkv, dec->qkv, batch, H, QKV, false, nullptr, false, stream));
         // :100 RoPE at position step-1
-        if ((rc = llmie_rope_decode(dec->qkv, batch, c.head_num, c.kv_head_num, c.head_size, step, step_dev,
-                                    c.rotary_dim, c.rotary_base, dt, stream)))
-            return rc;
+        TIMED(LLMIE_OP_ROPE, llmie_rope_decode(dec->qkv, batch, c.head_num, c.kv_head_num, c.head_size, step, step_dev,
+                                               c.rotary_dim, c.rotary_base, dt, stream));
         // :108 fused masked MHA with KV append
-        if ((rc = llmie_decoder_mha(dec->qkv, w.qkv.bias, k_cache, v_cache, dec->mha, l, batch, c.head_num,
-                                    c.kv_head_num, c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws,
-                                    dec->attn_ws_bytes, dt, stream)))
-            return rc;
+        TIMED(LLMIE_OP_MHA, llmie_decoder_mha(dec->qkv, w.qkv.bias, k_cache, v_cache, dec->mha, l, batch, c.head_num,
+                                              c.kv_head_num, c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws,
+                                              dec->attn_ws_bytes, dt, stream));
         // :131 output projection (no bias here: the fused norm below adds o.bias, self_decoder.cpp:92-98)
-        if ((rc = engine_linear(dec, c.wfmt, dec->mha, w.o, h, batch, H, H, false, nullptr, false, stream))) return rc;
+        TIMED(LLMIE_OP_O_GEMM, engine_linear(dec, c.wfmt, dec->mha, w.o, h, batch, H, H, false, nullptr, false, stream));
         // self_decoder.cpp:92  h += resid; resid = h; h += o.bias; h = rmsnorm(h, ffn_gamma)
-        if ((rc = llmie_fused_add_bias_residual_rmsnorm(dec->resid, h, w.o.bias, w.ffn_norm_gamma, c.rms_eps, batch, H,
-                                                        dt, stream)))
-            return rc;
+        TIMED(LLMIE_OP_FFN_NORM, llmie_fused_add_bias_residual_rmsnorm(dec->resid, h, w.o.bias, w.ffn_norm_gamma,
+                                                                       c.rms_eps, batch, H, dt, stream));
         // ffn.cpp:105-122  act = silu(h.Wg^T) * (h.Wu^T)
-        if ((rc = engine_linear(dec, c.wfmt, h, w.gate_up, dec->act, batch, H, 2 * I, true, nullptr, false, stream))) return rc;
+        TIMED(LLMIE_OP_GATE_UP_SWIGLU, engine_linear(dec, c.wfmt, h, w.gate_up, dec->act, batch, H, 2 * I, true, nullptr, false, stream));
         // ffn.cpp:132 + self_decoder.cpp:111  h = act . Wd^T + resid
-        if ((rc = engine_linear(dec, c.wfmt, dec->act, w.down, h, batch, I, H, false, dec->resid, false, stream))) return rc;
+        TIMED(LLMIE_OP_DOWN_GEMM, engine_linear(dec, c.wfmt, dec->act, w.down, h, batch, I, H, false, dec->resid, false, stream));
     }
     return LLMIE_OK;
 }
@@ -228,15 +296,14 @@ extern "C" int llmie_lm_head_sample(llmie_decoder *dec, void *hidden, const void
     LLMIE_REQUIRE(c.vocab_size > 0, "lm_head_sample: vocab_size not set in the decoder config");
     int rc;
     // llama.cpp:247  final RMSNorm (the residual copy is unused there: pass NULL)
-    if ((rc = llmie_rmsnorm(hidden, nullptr, final_norm_gamma, c.rms_eps, batch, dec->H, c.dtype, stream))) return rc;
+    TIMED(LLMIE_OP_FINAL_NORM, llmie_rmsnorm(hidden, nullptr, final_norm_gamma, c.rms_eps, batch, dec->H, c.dtype, stream));
     // llama.cpp:282  logits = hidden . lm_head^T
-    if ((rc = engine_linear(dec, lm_fmt, hidden, *lm_head, logits, batch, dec->H, c.vocab_size, false, nullptr, false,
-                            stream)))
-        return rc;
+    TIMED(LLMIE_OP_LM_HEAD, engine_linear(dec, lm_fmt, hidden, *lm_head, logits, batch, dec->H, c.vocab_size, false, nullptr,
+                                          false, stream));
     // llama.cpp:293,304
-    if ((rc = llmie_topk(logits, tmp_ids, tmp_vals, topk_ids, topk_vals, batch, c.vocab_size, K, blocks_per_row, c.dtype,
-                         stream)))
-        return rc;
-    return llmie_sampling(topk_ids, topk_vals, seq_len, finished, out_ids, batch, K, step, step_dev, end_id,
-                          c.vocab_size, c.dtype, stream);
+    TIMED(LLMIE_OP_TOPK, llmie_topk(logits, tmp_ids, tmp_vals, topk_ids, topk_vals, batch, c.vocab_size, K, blocks_per_row,
+                                    c.dtype, stream));
+    TIMED(LLMIE_OP_SAMPLING, llmie_sampling(topk_ids, topk_vals, seq_len, finished, out_ids, batch, K, step, step_dev, end_id,
+                                            c.vocab_size, c.dtype, stream));
+    return LLMIE_OK;
 }

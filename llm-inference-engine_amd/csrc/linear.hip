@@ -131,6 +131,15 @@ extern "C" int llmie_linear(const void *x, const void *w, void *y, int M, int K,
     LLMIE_UNSUPPORTED("linear: dtype %d", (int)dtype);
 }
 
+extern "C" int llmie_linear_swiglu(const void *x, const void *w, void *y, int M, int K, int two_inter,
+                                   llmie_dtype dtype, llmie_stream stream) {
+    LLMIE_REQUIRE(x && w && y, "linear_swiglu: NULL pointer");
+    LLMIE_REQUIRE(M > 0 && K > 0 && two_inter > 0 && two_inter % 2 == 0, "linear_swiglu: bad shape");
+    if (dtype != LLMIE_F16) LLMIE_UNSUPPORTED("linear_swiglu: fp16 only (dtype %d)", (int)dtype);
+    return linear_f16_nk((const half_t *)x, (const half_t *)w, (half_t *)y, M, K, two_inter, EPI_SWIGLU, nullptr,
+                         nullptr, as_stream(stream));
+}
+
 extern "C" int llmie_batched_gemm(const void *a, const void *b, void *c, int batch, int m, int n, int k,
                                   int trans_b, llmie_dtype dtype, llmie_stream stream) {
     LLMIE_REQUIRE(a && b && c, "batched_gemm: NULL pointer");
