@@ -1,0 +1,286 @@
+// Layer-level tests through the C++ API mirror (LlamaSelfDecoder / LlamaContextDecoder / LlamaFFNLayer /
+// LlamaModel with the reference's constructor arguments and TensorMap keys), checked against compositions of
+// the oracle's kernels:   ./test_layers_api [1 = fp16]
+#include "../src/layers/includes/context_decoder.h"
+#include "../src/layers/includes/self_decoder.h"
+#include "../src/utils/model_utils.h"
+#include "test_common.hpp"
+
+struct HostLayer {
+    std::vector<float> attn_norm, qkv, o, o_bias, ffn_norm, gate_up, down;
+};
+
+template <typename T> struct Model {
+    int nh, kvh, hs, I, L, H, QKV;
+    std::vector<HostLayer> host;
+    std::vector<std::unique_ptr<LlamaLayerWeight<T>>> dev;
+    std::vector<LlamaLayerWeight<T> *> ptrs;
+    std::vector<orc_layer_weights> orc;
+
+    Model(int nh_, int kvh_, int hs_, int I_, int L_, bool o_bias, bool hf_layout_flags, uint64_t seed)
+        : nh(nh_), kvh(kvh_), hs(hs_), I(I_), L(L_), H(nh_ * hs_), QKV((nh_ + 2 * kvh_) * hs_) {
+        std::mt19937_64 rng(seed);
+        for (int l = 0; l < L; ++l) {
+            HostLayer h;
+            h.attn_norm = randu(rng, H, 0.2f);
+            h.ffn_norm = randu(rng, H, 0.2f);
+            for (auto &v : h.attn_norm) v += 1.f;
+            for (auto &v : h.ffn_norm) v += 1.f;
+            h.attn_norm = storage_round<T>(h.attn_norm);
+            h.ffn_norm = storage_round<T>(h.ffn_norm);
+            h.qkv = storage_round<T>(randu(rng, static_cast<size_t>(QKV) * H, 2.f / std::sqrt(static_cast<float>(H))));
+            h.o = storage_round<T>(randu(rng, static_cast<size_t>(H) * H, 2.f / std::sqrt(static_cast<float>(H))));
+            if (o_bias) h.o_bias = storage_round<T>(randu(rng, H, 0.1f));
+            h.gate_up = storage_round<T>(randu(rng, static_cast<size_t>(2 * I) * H, 2.f / std::sqrt(static_cast<float>(H))));
+            h.down = storage_round<T>(randu(rng, static_cast<size_t>(H) * I, 2.f / std::sqrt(static_cast<float>(I))));
+            host.push_back(std::move(h));
+        }
+        for (int l = 0; l < L; ++l) {
+            auto w = std::make_unique<LlamaLayerWeight<T>>(nh, kvh, hs, I, getWeightType<T>(), o_bias);
+            const HostLayer &h = host[l];
+            llmie_api::upload(w->attention_norm_weight.gamma, cast_vec<T>(h.attn_norm));
+            llmie_api::upload(w->ffn_norm_weight.gamma, cast_vec<T>(h.ffn_norm));
+            llmie_api::upload(w->self_attention_weight.qkv.data, cast_vec<T>(h.qkv));
+            llmie_api::upload(w->self_attention_weight.output.data, cast_vec<T>(h.o));
+            if (o_bias) llmie_api::upload(w->self_attention_weight.output.bias, cast_vec<T>(h.o_bias));
+            if (w->self_attention_weight.qkv.bias) {  // allocated by attention_bias=true but Llama has no qkv bias
+                GPUFree(w->self_attention_weight.qkv.bias);
+                w->self_attention_weight.qkv.bias = nullptr;
+            }
+            llmie_api::upload(w->ffn_weight.gate_and_up.data, cast_vec<T>(h.gate_up));
+            llmie_api::upload(w->ffn_weight.down.data, cast_vec<T>(h.down));
+            w->self_attention_weight.qkv.is_transposed = true;
+            w->self_attention_weight.output.is_transposed = true;
+            w->ffn_weight.gate_and_up.is_transposed = true;
+            w->ffn_weight.down.is_transposed = hf_layout_flags;  // all four true -> the fused engine is eligible
+            ptrs.push_back(w.get());
+            dev.push_back(std::move(w));
+            orc_layer_weights ow{};
+            ow.attn_norm = host[l].attn_norm.data();
+            ow.qkv = host[l].qkv.data();
+            ow.o = host[l].o.data();
+            ow.o_bias = o_bias ? host[l].o_bias.data() : nullptr;
+            ow.ffn_norm = host[l].ffn_norm.data();
+            ow.gate_up = host[l].gate_up.data();
+            ow.down = host[l].down.data();
+            orc.push_back(ow);
+        }
+    }
+};
+
+// oracle composition of LlamaContextDecoder::forward (context_decoder.cpp:58-199, context_attention.cpp:143-312)
+template <typename T>
+static void oracle_context_decoder(const Model<T> &m, std::vector<float> &hidden /*[Tn,H] in/out*/, std::vector<float> &kc,
+                                   std::vector<float> &vc, const std::vector<int> &lens, const std::vector<int> &hist,
+                                   int max_seq, int rot_dim, float rot_base, float eps) {
+    const int bs = static_cast<int>(lens.size());
+    int Tn = 0, mq = 0, mk = 0;
+    std::vector<int> ctx(bs);
+    for (int b = 0; b < bs; ++b) {
+        Tn += lens[b];
+        mq = std::max(mq, lens[b]);
+        ctx[b] = lens[b] + hist[b];
+        mk = std::max(mk, ctx[b]);
+    }
+    const int nh = m.nh, kvh = m.kvh, hs = m.hs, H = m.H, QKV = m.QKV, I = m.I;
+    std::vector<int> off(static_cast<size_t>(bs) * mq, 0), cum(bs + 1);
+    orc_cal_padding_offset(off.data(), cum.data(), lens.data(), bs, mq);
+    std::vector<float> mask(static_cast<size_t>(bs) * mq * mk);
+    orc_build_causal_mask(mask.data(), lens.data(), ctx.data(), bs, mq, mk);
+    std::vector<float> resid(hidden.size()), qkv(static_cast<size_t>(Tn) * QKV), attn(static_cast<size_t>(Tn) * H);
+    std::vector<float> gu(static_cast<size_t>(Tn) * 2 * I), act(static_cast<size_t>(Tn) * I);
+    for (int l = 0; l < m.L; ++l) {
+        const orc_layer_weights &w = m.orc[l];
+        orc_rmsnorm(hidden.data(), resid.data(), w.attn_norm, eps, Tn, H);
+        orc_linear(hidden.data(), w.qkv, qkv.data(), Tn, H, QKV, 1);
+        std::vector<float> q(static_cast<size_t>(bs) * nh * mq * hs, 0.f), k(static_cast<size_t>(bs) * kvh * mq * hs, 0.f), v(k.size(), 0.f);
+        orc_qkv_bias_transpose_rope(q.data(), k.data(), v.data(), qkv.data(), nullptr, off.data(), hist.data(), bs, mq, Tn,
+                                    nh, kvh, hs, rot_dim, rot_base);
+        orc_concat_kv(k.data(), kc.data(), lens.data(), hist.data(), l, bs, kvh, mq, max_seq, hs);
+        orc_concat_kv(v.data(), vc.data(), lens.data(), hist.data(), l, bs, kvh, mq, max_seq, hs);
+        std::vector<float> kr(static_cast<size_t>(bs) * nh * mk * hs, 0.f), vr(kr.size(), 0.f);
+        orc_repeat_kv(kc.data(), kr.data(), ctx.data(), l, bs, nh, kvh, mk, max_seq, hs);
+        orc_repeat_kv(vc.data(), vr.data(), ctx.data(), l, bs, nh, kvh, mk, max_seq, hs);
+        std::vector<float> qk(static_cast<size_t>(bs) * nh * mq * mk), pv(static_cast<size_t>(bs) * nh * mq * hs);
+        orc_batched_gemm(q.data(), kr.data(), qk.data(), bs * nh, mq, mk, hs, 1);
+        orc_scale_mask_softmax(qk.data(), mask.data(), qk.data(), 1.0f / std::sqrt(static_cast<float>(hs)), bs, nh, mq, mk);
+        orc_batched_gemm(qk.data(), vr.data(), pv.data(), bs * nh, mq, hs, mk, 0);
+        orc_transpose_remove_padding(pv.data(), attn.data(), off.data(), Tn, bs, mq, nh, hs);
+        orc_linear(attn.data(), w.o, hidden.data(), Tn, H, H, 1);
+        orc_fused_add_bias_residual_rmsnorm(resid.data(), hidden.data(), w.o_bias, w.ffn_norm, eps, Tn, H);
+        orc_linear(hidden.data(), w.gate_up, gu.data(), Tn, H, 2 * I, 1);
+        orc_silu_and_mul(gu.data(), act.data(), Tn, I);
+        orc_linear(act.data(), w.down, hidden.data(), Tn, I, H, 1);
+        orc_add_residual(resid.data(), hidden.data(), Tn, H);
+    }
+}
+
+template <typename T> static void run(bool fp16) {
+    const DataType ty = getTensorType<T>(), ti = getTensorType<int>();
+    const float rt = fp16 ? 2e-2f : 2e-4f, at = fp16 ? 2e-2f : 2e-4f;
+    const int nh = fp16 ? 8 : 4, kvh = fp16 ? 4 : 4, hs = fp16 ? 128 : 32, I = fp16 ? 1376 : 344, L = 2;
+    const int max_seq = 48, rot = hs;
+    const float eps = 1e-5f, base = 10000.f;
+    CublasWrapper gemm;
+    CudaAllocator alloc;
+    LlamaAttentionStaticParams sp{};
+    sp.rotary_embedding_dim = rot;
+    sp.rotary_embedding_base = base;
+    sp.max_position_embeddings = 2048;
+    sp.use_dynamic_ntk = false;
+    hipStream_t stream = nullptr;
+
+    for (int variant = 0; variant < 2; ++variant) {
+        // variant 0: HF layout flags -> fused engine; variant 1: force the per-kernel loop (the reference's sequence)
+        Model<T> m(nh, kvh, hs, I, L, /*o_bias=*/true, /*hf flags*/ true, 77);
+        const int H = m.H, bs = 2, step = 9;
+        std::mt19937_64 rng(5);
+        std::vector<float> x = storage_round<T>(randn(rng, static_cast<size_t>(bs) * H, 1.f));
+        std::vector<float> kc = storage_round<T>(randn(rng, static_cast<size_t>(L) * bs * kvh * max_seq * hs, 0.5f));
+        std::vector<float> vc = storage_round<T>(randn(rng, kc.size(), 0.5f));
+        DeviceArray<T> din(cast_vec<T>(x)), dout(x.size()), dk(cast_vec<T>(kc)), dv(cast_vec<T>(vc));
+        DeviceArray<bool> dfin(bs);
+        int h_step = step, h_layer = 0;
+        TensorWrapper<T> tin(Device::GPU, ty, {bs, H}, din.d), tout(Device::GPU, ty, {bs, H}, dout.d);
+        TensorWrapper<T> tk(Device::GPU, ty, {L, bs, kvh, max_seq, hs}, dk.d), tv(Device::GPU, ty, {L, bs, kvh, max_seq, hs}, dv.d);
+        TensorWrapper<int> tstep(Device::CPU, ti, {1}, &h_step), tlayer(Device::CPU, ti, {1}, &h_layer);
+        TensorWrapper<bool> tfin(Device::GPU, getTensorType<bool>(), {bs}, dfin.d);
+        TensorMap inputs{{"decoder_input", &tin}, {"step", &tstep}, {"finished", &tfin}, {"layer_id", &tlayer}};
+        TensorMap outputs{{"decoder_output", &tout}, {"all_k_cache", &tk}, {"all_v_cache", &tv}};
+        LlamaAttentionDynamicParams dyn{};
+        dyn.batch_size = bs;
+        LlamaSelfDecoder<T> dec(nh, kvh, hs, I, L, sp, eps, stream, &gemm, &alloc);
+        dec.use_fused_engine = (variant == 0);
+        dec.forward(&inputs, &m.ptrs, &outputs, &dyn);
+        orc_llama_cfg oc{nh, kvh, hs, I, L, 0, max_seq, rot, base, eps};
+        std::vector<float> scratch(static_cast<size_t>(bs) * (2 * H + m.QKV + 3 * I));
+        orc_self_decoder(&oc, m.orc.data(), x.data(), kc.data(), vc.data(), bs, step, scratch.data());
+        check_close(variant == 0 ? "LlamaSelfDecoder (fused engine)" : "LlamaSelfDecoder (per-kernel loop)",
+                    to_float(dout.download()), x, rt, at);
+        check_close("LlamaSelfDecoder k cache", to_float(dk.download()), kc, fp16 ? rt : 1e-5f, fp16 ? at : 1e-5f);
+    }
+
+    {   // prefill: ragged batch with history, against the oracle composition; then prefill/decode consistency
+        Model<T> m(nh, kvh, hs, I, L, /*o_bias=*/false, true, 99);
+        const int H = m.H;
+        const std::vector<int> lens{5, 3}, hist{0, 2};
+        const int bs = 2, Tn = 8, mq = 5, mk = 5;
+        std::mt19937_64 rng(6);
+        std::vector<float> x = storage_round<T>(randn(rng, static_cast<size_t>(Tn) * H, 1.f));
+        std::vector<float> kc = storage_round<T>(randn(rng, static_cast<size_t>(L) * bs * kvh * max_seq * hs, 0.5f));
+        std::vector<float> vc = storage_round<T>(randn(rng, kc.size(), 0.5f));
+        DeviceArray<T> din(cast_vec<T>(x)), dout(x.size()), dk(cast_vec<T>(kc)), dv(cast_vec<T>(vc));
+        std::vector<int> ctx{5, 5};
+        DeviceArray<int> dlen(lens), dhist(hist), dctx(ctx);
+        int h_layer = 0;
+        TensorWrapper<T> tin(Device::GPU, ty, {Tn, H}, din.d), tout(Device::GPU, ty, {Tn, H}, dout.d);
+        TensorWrapper<T> tk(Device::GPU, ty, {L, bs, kvh, max_seq, hs}, dk.d), tv(Device::GPU, ty, {L, bs, kvh, max_seq, hs}, dv.d);
+        TensorWrapper<int> tlen(Device::GPU, ti, {bs}, dlen.d), thist(Device::GPU, ti, {bs}, dhist.d), tctx(Device::GPU, ti, {bs}, dctx.d);
+        TensorWrapper<int> tlayer(Device::CPU, ti, {1}, &h_layer);
+        TensorMap inputs{{"decoder_input", &tin}, {"history_length", &thist}, {"input_length", &tlen},
+                         {"context_length", &tctx}, {"layer_id", &tlayer}};
+        TensorMap outputs{{"decoder_output", &tout}, {"all_k_cache", &tk}, {"all_v_cache", &tv}};
+        LlamaAttentionDynamicParams dyn{};
+        dyn.batch_size = bs;
+        dyn.num_tokens = Tn;
+        dyn.max_q_len = mq;
+        dyn.max_k_len = mk;
+        LlamaContextDecoder<T> cdec(nh, kvh, hs, I, L, &sp, eps, stream, &gemm, &alloc);
+        cdec.forward(&inputs, &m.ptrs, &outputs, &dyn);
+        oracle_context_decoder(m, x, kc, vc, lens, hist, max_seq, rot, base, eps);
+        check_close("LlamaContextDecoder", to_float(dout.download()), x, rt, at);
+        // layer >= 1 K rows come out of a full fp16 layer: same tolerance as the hidden state
+        check_close("LlamaContextDecoder k cache", to_float(dk.download()), kc, fp16 ? rt : 1e-5f, fp16 ? at : 1e-5f);
+        // the decoder object is reusable (the reference deletes its sub-layers in freeBuf)
+        cdec.freeBuf();
+        din.upload(cast_vec<T>(storage_round<T>(x)));
+        cdec.forward(&inputs, &m.ptrs, &outputs, &dyn);
+        std::printf("LlamaContextDecoder reuse passed\n");
+    }
+    {   // prefill(n+1 tokens) last row == prefill(n tokens) then one decode step   (same kernels family, two paths)
+        Model<T> m(nh, kvh, hs, I, L, false, true, 123);
+        const int H = m.H, n = 6;
+        std::mt19937_64 rng(7);
+        std::vector<float> xs = storage_round<T>(randn(rng, static_cast<size_t>(n + 1) * H, 1.f));
+        const size_t kvn = static_cast<size_t>(L) * kvh * max_seq * hs;
+        auto prefill = [&](int tokens, DeviceArray<T> &dk, DeviceArray<T> &dv) {
+            std::vector<float> in(xs.begin(), xs.begin() + static_cast<size_t>(tokens) * H);
+            DeviceArray<T> din(cast_vec<T>(in)), dout(in.size());
+            std::vector<int> lens{tokens}, hist{0};
+            DeviceArray<int> dlen(lens), dhist(hist), dctx(lens);
+            int h_layer = 0;
+            TensorWrapper<T> tin(Device::GPU, ty, {tokens, H}, din.d), tout(Device::GPU, ty, {tokens, H}, dout.d);
+            TensorWrapper<T> tk(Device::GPU, ty, {L, 1, kvh, max_seq, hs}, dk.d), tv(Device::GPU, ty, {L, 1, kvh, max_seq, hs}, dv.d);
+            TensorWrapper<int> tlen(Device::GPU, ti, {1}, dlen.d), thist(Device::GPU, ti, {1}, dhist.d), tctx(Device::GPU, ti, {1}, dctx.d);
+            TensorWrapper<int> tlayer(Device::CPU, ti, {1}, &h_layer);
+            TensorMap inputs{{"decoder_input", &tin}, {"history_length", &thist}, {"input_length", &tlen},
+                             {"context_length", &tctx}, {"layer_id", &tlayer}};
+            TensorMap outputs{{"decoder_output", &tout}, {"all_k_cache", &tk}, {"all_v_cache", &tv}};
+            LlamaAttentionDynamicParams dyn{};
+            dyn.batch_size = 1;
+            dyn.num_tokens = tokens;
+            dyn.max_q_len = tokens;
+            dyn.max_k_len = tokens;
+            LlamaContextDecoder<T> cdec(nh, kvh, hs, I, L, &sp, eps, stream, &gemm, &alloc);
+            cdec.forward(&inputs, &m.ptrs, &outputs, &dyn);
+            std::vector<float> all = to_float(dout.download());
+            return std::vector<float>(all.end() - H, all.end());
+        };
+        DeviceArray<T> k1(kvn), v1(kvn), k2(kvn), v2(kvn);
+        CHECK(hipMemset(k1.d, 0, sizeof(T) * kvn)); CHECK(hipMemset(v1.d, 0, sizeof(T) * kvn));
+        CHECK(hipMemset(k2.d, 0, sizeof(T) * kvn)); CHECK(hipMemset(v2.d, 0, sizeof(T) * kvn));
+        const std::vector<float> full = prefill(n + 1, k1, v1);
+        (void)prefill(n, k2, v2);
+        std::vector<float> last(xs.end() - H, xs.end());
+        DeviceArray<T> din(cast_vec<T>(last)), dout(H);
+        DeviceArray<bool> dfin(1);
+        int h_step = n + 1, h_layer = 0;
+        TensorWrapper<T> tin(Device::GPU, ty, {1, H}, din.d), tout(Device::GPU, ty, {1, H}, dout.d);
+        TensorWrapper<T> tk(Device::GPU, ty, {L, 1, kvh, max_seq, hs}, k2.d), tv(Device::GPU, ty, {L, 1, kvh, max_seq, hs}, v2.d);
+        TensorWrapper<int> tstep(Device::CPU, ti, {1}, &h_step), tlayer(Device::CPU, ti, {1}, &h_layer);
+        TensorWrapper<bool> tfin(Device::GPU, getTensorType<bool>(), {1}, dfin.d);
+        TensorMap inputs{{"decoder_input", &tin}, {"step", &tstep}, {"finished", &tfin}, {"layer_id", &tlayer}};
+        TensorMap outputs{{"decoder_output", &tout}, {"all_k_cache", &tk}, {"all_v_cache", &tv}};
+        LlamaAttentionDynamicParams dyn{};
+        dyn.batch_size = 1;
+        LlamaSelfDecoder<T> dec(nh, kvh, hs, I, L, sp, eps, stream, &gemm, &alloc);
+        dec.forward(&inputs, &m.ptrs, &outputs, &dyn);
+        check_close("prefill(n+1) last row == prefill(n) + decode step", to_float(dout.download()), full, rt, at);
+        check_close("KV caches agree after both paths", to_float(k2.download()), to_float(k1.download()), fp16 ? rt : 1e-5f, fp16 ? at : 1e-5f);
+    }
+    {   // the user_entry.cpp flow: llm::createDummyLLMModel -> MakeInput -> Response(callback) -> MakeHistory
+        llm::ModelConfig &c = llm::config();
+        c.head_num = 4; c.kv_head_num = 4; c.head_size = 32; c.inter_size = 344; c.num_layers = 2;
+        c.max_seq_len = 64; c.vocab_size = 30000; c.rotary_embedding_dim = 32;
+        srand(42);
+        std::unique_ptr<BaseModel> model(llm::createDummyLLMModel<T>("/nonexistent/tokenizer.bin"));
+        int calls = 0, last_index = -2;
+        bool ended = false;
+        auto cb = [&](int index, const char *content) {
+            (void)content;
+            if (index == -1) ended = true; else { ++calls; last_index = index; }
+        };
+        const std::string reply = model->Response(model->MakeInput("", 0, "Hey, are you conscious? Can you talk to me?"), cb);
+        const std::string hist = model->MakeHistory("", 0, "Hey", reply);
+        const bool ok = ended && calls >= 1 && calls <= 20 && last_index == calls - 1 && !reply.empty() && hist.size() >= reply.size() && model->model_name == "llama";
+        std::printf(ok ? "LlamaModel Response/MakeInput/MakeHistory passed (%d tokens)\n" : "FAIL LlamaModel chat flow (%d tokens)\n", calls);
+        if (!ok) ++g_failures;
+        const std::vector<int> first = static_cast<LlamaModel<T> *>(model.get())->last_token_ids;
+        (void)model->response(model->makeInput("", 0, "again"), nullptr);
+        const std::vector<int> second = static_cast<LlamaModel<T> *>(model.get())->last_token_ids;
+        check_equal("LlamaModel deterministic tokens", second, first);
+    }
+}
+
+int main(int argc, char **) {
+    try {
+        if (argc > 1) run<half>(true);
+        else run<float>(false);
+    } catch (const std::exception &e) {
+        std::printf("FAIL: exception %s\n", e.what());
+        return 2;
+    }
+    CHECK(hipDeviceSynchronize());
+    std::printf(g_failures ? "%d FAILED\n" : "all passed (%d failures)\n", g_failures);
+    return g_failures ? 1 : 0;
+}

@@ -1,0 +1,3 @@
+// Same relative path as the reference header; the implementation lives in api/weights.hpp
+#pragma once
+#include "../../../api/weights.hpp"
