@@ -265,7 +265,7 @@ int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, void *hidde
 
 /* LM head + top-k + sampling tail (llama.cpp:247-318): final RMSNorm(gamma) -> logits =
  * x . lm_head[V,H]^T -> top-K -> sample.  logits[bs,V] and topk buffers caller-owned. */
-int llmie_lm_head_sample(llmie_decoder *dec, void *hidden /* [bs,H], normalised in place */,
+int llmie_lm_head_sample(llmie_decoder *dec, void *hidden /* [bs,H]; clobbered (may be normalised in place) */,
                          const void *final_norm_gamma, const llmie_matrix *lm_head,
                          llmie_weight_format lm_fmt, void *logits,
                          int32_t *tmp_ids, void *tmp_vals, int32_t *topk_ids, void *topk_vals,

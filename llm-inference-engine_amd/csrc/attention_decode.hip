@@ -33,7 +33,8 @@ template <typename T, int HS, int REP>
 __global__ __launch_bounds__(256) void decode_attn_split_kernel(
     const T *__restrict__ qkv, const T *__restrict__ qkv_bias, T *k_cache, T *v_cache,
     float *__restrict__ part, T *__restrict__ out, int head_num, int kv_head_num, int max_seq_len,
-    int step_arg, const int32_t *__restrict__ step_dev, int max_splits) {
+    int step_arg, const int32_t *__restrict__ step_dev, int max_splits,
+    const float2 *__restrict__ rope /* [max_pos][HS/2] (cos,sin) or null */, int rotary_dim) {
     using G = AttnGeom<T, HS>;
     using V = typename Vec16<T>::type;
     constexpr int N = G::N, LPT = G::LPT, TPW = G::TPW, CHUNK = G::CHUNK;
@@ -54,22 +55,49 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
 
     const T *row = qkv + static_cast<size_t>(b) * qkv_heads * HS;
     // q for the REP heads of this kv head, pre-scaled, fp32
+    // RoPE (fused form of launchRope, rope.cu:4-43): rotate-half pairs (d, d+HS/2) live LPT/2 lanes apart
+    const int t_new = step - 1;
+    const bool rope_first = dl < LPT / 2;
+    float rc[N], rs[N];
+    if (rope) {
+        const float2 *cs = rope + static_cast<size_t>(t_new) * (HS / 2) + (dl % (LPT / 2)) * N;
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const bool rot = ((dl % (LPT / 2)) * N + e) < (rotary_dim >> 1);
+            const float2 v = rot ? cs[e] : float2{1.f, 0.f};
+            rc[e] = v.x;
+            rs[e] = rope_first ? -v.y : v.y;
+        }
+    }
+    auto rotate = [&](float (&x)[N]) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const float partner = __shfl_xor(x[e], LPT / 2, 64);
+            x[e] = x[e] * rc[e] + partner * rs[e];
+        }
+    };
     float qf[REP][N];
 #pragma unroll
     for (int r = 0; r < REP; ++r) {
         const int h = g * REP + r;
         V qv = reinterpret_cast<const V *>(row + static_cast<size_t>(h) * HS)[dl];
+        float f[N];
+#pragma unroll
+        for (int e = 0; e < N; ++e) f[e] = to_f32(qv[e]);
+        if (rope) {
+            rotate(f);
+#pragma unroll
+            for (int e = 0; e < N; ++e) f[e] = to_f32(from_f32<T>(f[e]));  // as stored by the unfused RoPE kernel
+        }
 #pragma unroll
         for (int e = 0; e < N; ++e) {
-            float f = to_f32(qv[e]);
-            if (qkv_bias) f += to_f32(qkv_bias[static_cast<size_t>(h) * HS + dl * N + e]);
-            qf[r][e] = f * scale;
+            if (qkv_bias) f[e] += to_f32(qkv_bias[static_cast<size_t>(h) * HS + dl * N + e]);
+            qf[r][e] = f[e] * scale;
         }
     }
     const size_t head_off = (static_cast<size_t>(b) * kv_head_num + g) * max_seq_len * HS;
     T *kc = k_cache + head_off;
     T *vc = v_cache + head_off;
-    const int t_new = step - 1;
 
     // ---- issue every K and V load of this wave's token range ----
     V kv[kAttnG], vv[kAttnG];
@@ -92,6 +120,15 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
             const int hk = head_num + g, hv = head_num + kv_head_num + g;
             V kn = reinterpret_cast<const V *>(row + static_cast<size_t>(hk) * HS)[dl];
             V vn = reinterpret_cast<const V *>(row + static_cast<size_t>(hv) * HS)[dl];
+            if (rope) {
+                // every lane of the wave takes part in the shuffles: only lanes of this token keep the result
+                float f[N];
+#pragma unroll
+                for (int e = 0; e < N; ++e) f[e] = to_f32(kn[e]);
+                rotate(f);
+#pragma unroll
+                for (int e = 0; e < N; ++e) kn[e] = from_f32<T>(f[e]);
+            }
             if (qkv_bias) {
 #pragma unroll
                 for (int e = 0; e < N; ++e) {
@@ -204,29 +241,39 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
     (void)batch;
 }
 
-// merge the per-split partials: grid (head_num, batch), block = 64..256 threads over hs
+// merge the per-split partials: grid (head_num, batch), 128 threads.  Split weights are computed once
+// in parallel (lane per split) and kept in LDS; the hs outputs then accumulate over the splits with all
+// loads independent, so the kernel costs about one L2 round trip.
 template <typename T>
-__global__ __launch_bounds__(256) void decode_attn_combine_kernel(const float *__restrict__ part,
+__global__ __launch_bounds__(128) void decode_attn_combine_kernel(const float *__restrict__ part,
                                                                   T *__restrict__ out, int head_num,
                                                                   int head_size, int chunk, int step_arg,
                                                                   const int32_t *__restrict__ step_dev,
                                                                   int max_splits) {
+    extern __shared__ float w_s[];  // [nsplits] un-normalised split weights
+    __shared__ float red[2];
     const int step = step_dev ? *step_dev : step_arg;
     const int nsplits = (step + chunk - 1) / chunk;
     if (nsplits <= 1) return;  // the split kernel already wrote the final output
     const int h = blockIdx.x, b = blockIdx.y;
-    const float *p = part + (static_cast<size_t>(b) * head_num + h) * max_splits * (head_size + 2);
-    float M = -INFINITY;
-    for (int s = 0; s < nsplits; ++s) M = fmaxf(M, p[static_cast<size_t>(s) * (head_size + 2)]);
-    for (int d = threadIdx.x; d < head_size; d += blockDim.x) {
-        float L = 0.f, o = 0.f;
-        for (int s = 0; s < nsplits; ++s) {
-            const float *ps = p + static_cast<size_t>(s) * (head_size + 2);
-            const float f = __expf(ps[0] - M);
-            L += f * ps[1];
-            o += f * ps[2 + d];
-        }
-        out[(static_cast<size_t>(b) * head_num + h) * head_size + d] = from_f32<T>(o / (L + 1e-6f));
+    const size_t stride = static_cast<size_t>(head_size) + 2;
+    const float *p = part + (static_cast<size_t>(b) * head_num + h) * max_splits * stride;
+    float m_loc = -INFINITY;
+    for (int s = threadIdx.x; s < nsplits; s += 128) m_loc = fmaxf(m_loc, p[s * stride]);
+    const float M = block_max<2>(m_loc, red);
+    float l_loc = 0.f;
+    for (int s = threadIdx.x; s < nsplits; s += 128) {
+        const float f = __expf(p[s * stride] - M);
+        w_s[s] = f;
+        l_loc += f * p[s * stride + 1];
+    }
+    const float L = block_sum<2>(l_loc, red);  // contains the barrier that publishes w_s
+    const float inv = 1.0f / (L + 1e-6f);
+    for (int d = threadIdx.x; d < head_size; d += 128) {
+        float o = 0.f;
+#pragma unroll 8
+        for (int s = 0; s < nsplits; ++s) o = fmaf(w_s[s], p[s * stride + 2 + d], o);
+        out[(static_cast<size_t>(b) * head_num + h) * head_size + d] = from_f32<T>(o * inv);
     }
 }
 
@@ -291,29 +338,30 @@ __global__ __launch_bounds__(256) void decode_attn_generic_kernel(
 template <typename T, int HS, int REP>
 static void launch_split(const T *qkv, const T *bias, T *kc, T *vc, float *part, T *out, int batch,
                          int head_num, int kv_head_num, int max_seq_len, int step, const int32_t *step_dev,
-                         int max_splits_ws, hipStream_t st) {
+                         int max_splits_ws, const float2 *rope, int rot_dim, hipStream_t st) {
     constexpr int CHUNK = AttnGeom<T, HS>::CHUNK;
     const int bound = step_dev ? max_seq_len : step;
     const int splits = (bound + CHUNK - 1) / CHUNK;
     dim3 grid(splits, kv_head_num, batch);
     decode_attn_split_kernel<T, HS, REP><<<grid, 256, 0, st>>>(qkv, bias, kc, vc, part, out, head_num,
-                                                               kv_head_num, max_seq_len, step, step_dev, max_splits_ws);
+                                                               kv_head_num, max_seq_len, step, step_dev, max_splits_ws,
+                                                               rope, rot_dim);
     if (splits > 1) {
         dim3 cgrid(head_num, batch);
-        decode_attn_combine_kernel<T><<<cgrid, HS < 64 ? 64 : (HS > 256 ? 256 : HS), 0, st>>>(
-            part, out, head_num, HS, CHUNK, step, step_dev, max_splits_ws);
+        decode_attn_combine_kernel<T><<<cgrid, 128, sizeof(float) * splits, st>>>(part, out, head_num, HS, CHUNK, step,
+                                                                                 step_dev, max_splits_ws);
     }
 }
 
 template <typename T, int HS>
 static bool dispatch_rep(int rep, const T *qkv, const T *bias, T *kc, T *vc, float *part, T *out, int batch,
                          int head_num, int kv_head_num, int max_seq_len, int step, const int32_t *step_dev,
-                         int max_splits_ws, hipStream_t st) {
+                         int max_splits_ws, const float2 *rope, int rot_dim, hipStream_t st) {
     switch (rep) {
-        case 1: launch_split<T, HS, 1>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, st); return true;
-        case 2: launch_split<T, HS, 2>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, st); return true;
-        case 4: launch_split<T, HS, 4>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, st); return true;
-        case 8: launch_split<T, HS, 8>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, st); return true;
+        case 1: launch_split<T, HS, 1>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, st); return true;
+        case 2: launch_split<T, HS, 2>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, st); return true;
+        case 4: launch_split<T, HS, 4>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, st); return true;
+        case 8: launch_split<T, HS, 8>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, st); return true;
         default: return false;
     }
 }
@@ -321,7 +369,8 @@ static bool dispatch_rep(int rep, const T *qkv, const T *bias, T *kc, T *vc, flo
 template <typename T>
 static int decoder_mha_impl(const T *qkv, const T *bias, T *k_cache, T *v_cache, T *out, int layer, int batch,
                             int head_num, int kv_head_num, int head_size, int max_seq_len, int step,
-                            const int32_t *step_dev, void *workspace, size_t workspace_bytes, hipStream_t st) {
+                            const int32_t *step_dev, void *workspace, size_t workspace_bytes, const float2 *rope,
+                            int rot_dim, hipStream_t st) {
     const size_t layer_off = static_cast<size_t>(layer) * batch * kv_head_num * max_seq_len * head_size;
     T *kc = k_cache + layer_off, *vc = v_cache + layer_off;
     const int rep = head_num / kv_head_num;
@@ -334,18 +383,22 @@ static int decoder_mha_impl(const T *qkv, const T *bias, T *k_cache, T *v_cache,
         float *part = static_cast<float *>(workspace);
         auto ws_ok = [&]() { return workspace && workspace_bytes >= need; };
         if (head_size == 128 && ws_ok())
-            done = dispatch_rep<T, 128>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, st);
+            done = dispatch_rep<T, 128>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, st);
         else if (head_size == 64 && ws_ok())
-            done = dispatch_rep<T, 64>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, st);
+            done = dispatch_rep<T, 64>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, st);
         else if (head_size == 32 && ws_ok())
-            done = dispatch_rep<T, 32>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, st);
+            done = dispatch_rep<T, 32>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, st);
         else if (head_size == 256 && ws_ok())
-            done = dispatch_rep<T, 256>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, st);
+            done = dispatch_rep<T, 256>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, st);
         if (!done && (head_size == 128 || head_size == 64 || head_size == 32 || head_size == 256) && !ws_ok() &&
             (rep == 1 || rep == 2 || rep == 4 || rep == 8)) {
             set_error("decoder_mha: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
             return LLMIE_ERR_WORKSPACE;
         }
+    }
+    if (!done && rope) {
+        set_error("decoder_mha: fused RoPE needs head_size in {32,64,128,256} and head_num/kv_head_num in {1,2,4,8}");
+        return LLMIE_ERR_UNSUPPORTED;
     }
     if (!done) {
         const int bound = step_dev ? max_seq_len : step;
@@ -359,6 +412,20 @@ static int decoder_mha_impl(const T *qkv, const T *bias, T *k_cache, T *v_cache,
                                                              head_size, max_seq_len, step, step_dev);
     }
     return launch_status("decoder_mha");
+}
+
+// engine entry: same as llmie_decoder_mha with RoPE (table [max_pos][hs/2] of (cos,sin)) fused in front
+int decoder_mha_rope(const void *qkv, const void *qkv_bias, void *k_cache, void *v_cache, void *out, int layer, int batch,
+                     int head_num, int kv_head_num, int head_size, int max_seq_len, int step, const int32_t *step_dev,
+                     void *workspace, size_t workspace_bytes, const float2 *rope, int rot_dim, llmie_dtype dtype,
+                     hipStream_t st) {
+    if (dtype == LLMIE_F32)
+        return decoder_mha_impl<float>((const float *)qkv, (const float *)qkv_bias, (float *)k_cache, (float *)v_cache,
+                                       (float *)out, layer, batch, head_num, kv_head_num, head_size, max_seq_len, step,
+                                       step_dev, workspace, workspace_bytes, rope, rot_dim, st);
+    return decoder_mha_impl<half_t>((const half_t *)qkv, (const half_t *)qkv_bias, (half_t *)k_cache, (half_t *)v_cache,
+                                    (half_t *)out, layer, batch, head_num, kv_head_num, head_size, max_seq_len, step,
+                                    step_dev, workspace, workspace_bytes, rope, rot_dim, st);
 }
 
 }  // namespace llmie
@@ -384,10 +451,10 @@ extern "C" int llmie_decoder_mha(const void *qkv, const void *qkv_bias, void *k_
     if (dtype == LLMIE_F32)
         return decoder_mha_impl<float>((const float *)qkv, (const float *)qkv_bias, (float *)k_cache, (float *)v_cache,
                                        (float *)out, layer, batch, head_num, kv_head_num, head_size, max_seq_len, step,
-                                       step_dev, workspace, workspace_bytes, as_stream(stream));
+                                       step_dev, workspace, workspace_bytes, nullptr, 0, as_stream(stream));
     if (dtype == LLMIE_F16)
         return decoder_mha_impl<half_t>((const half_t *)qkv, (const half_t *)qkv_bias, (half_t *)k_cache,
                                         (half_t *)v_cache, (half_t *)out, layer, batch, head_num, kv_head_num, head_size,
-                                        max_seq_len, step, step_dev, workspace, workspace_bytes, as_stream(stream));
+                                        max_seq_len, step, step_dev, workspace, workspace_bytes, nullptr, 0, as_stream(stream));
     LLMIE_UNSUPPORTED("decoder_mha: dtype %d", (int)dtype);
 }

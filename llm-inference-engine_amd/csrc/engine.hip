@@ -12,6 +12,8 @@
 //     the down GEMV (reference: launchSiluAndMul / launchAddResidual as separate kernels).
 #include "llmie_internal.h"
 
+#include <cmath>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -26,6 +28,7 @@ struct llmie_decoder {
     char *resid, *qkv, *mha, *normed, *act, *gu;
     void *attn_ws;
     size_t attn_ws_bytes;
+    float2 *rope_table;  // [max_seq_len][head_size/2] (cos, sin), host-computed at create
     // profiling (eager only)
     bool profiling = false;
     std::vector<hipEvent_t> ev;      // pairs: start, stop
@@ -81,7 +84,7 @@ struct Carve {
     }
 };
 
-static size_t carve(const llmie_decoder_config *c, size_t *offs /*[7]*/) {
+static size_t carve(const llmie_decoder_config *c, size_t *offs /*[8]*/) {
     const size_t e = c->dtype == LLMIE_F16 ? 2 : 4;
     const size_t B = c->max_batch, H = static_cast<size_t>(c->head_num) * c->head_size;
     const size_t QKV = static_cast<size_t>(c->head_num + 2 * c->kv_head_num) * c->head_size;
@@ -94,12 +97,13 @@ static size_t carve(const llmie_decoder_config *c, size_t *offs /*[7]*/) {
     offs[4] = k.take(B * I * e);        // act
     offs[5] = k.take(B * 2 * I * e);    // gate_up (unfused paths)
     offs[6] = k.take(llmie_decoder_mha_workspace_bytes(c->max_batch, c->head_num, c->head_size, c->max_seq_len));
+    offs[7] = k.take(static_cast<size_t>(c->max_seq_len) * (c->head_size / 2) * sizeof(float2));  // RoPE table
     return k.off;
 }
 
 extern "C" size_t llmie_decoder_workspace_bytes(const llmie_decoder_config *cfg) {
     if (!config_ok(cfg)) return 0;
-    size_t offs[7];
+    size_t offs[8];
     return carve(cfg, offs);
 }
 
@@ -113,7 +117,7 @@ extern "C" llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg, 
         set_error("decoder_create: NULL layers/workspace");
         return nullptr;
     }
-    size_t offs[7];
+    size_t offs[8];
     const size_t need = carve(cfg, offs);
     if (workspace_bytes < need) {
         set_error("decoder_create: workspace too small (%zu < %zu)", workspace_bytes, need);
@@ -152,6 +156,27 @@ extern "C" llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg, 
     d->gu = base + offs[5];
     d->attn_ws = base + offs[6];
     d->attn_ws_bytes = llmie_decoder_mha_workspace_bytes(cfg->max_batch, cfg->head_num, cfg->head_size, cfg->max_seq_len);
+    d->rope_table = reinterpret_cast<float2 *>(base + offs[7]);
+    {
+        // cos/sin of angle = pos / base^(2j/rot_dim) (rope_utils.cuh:6-19), evaluated on the host in fp32 with libm --
+        // one synchronous upload at create time (the only host<->device copy the engine ever does)
+        const int half = cfg->head_size / 2;
+        std::vector<float2> tab(static_cast<size_t>(cfg->max_seq_len) * half);
+        for (int pos = 0; pos < cfg->max_seq_len; ++pos)
+            for (int j = 0; j < half; ++j) {
+                float2 v{1.f, 0.f};
+                if (j < cfg->rotary_dim / 2) {
+                    const float ang = static_cast<float>(pos) / powf(cfg->rotary_base, static_cast<float>(2 * j) / static_cast<float>(cfg->rotary_dim));
+                    v = float2{cosf(ang), sinf(ang)};
+                }
+                tab[static_cast<size_t>(pos) * half + j] = v;
+            }
+        if (hipMemcpy(d->rope_table, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("decoder_create: RoPE table upload failed");
+            delete d;
+            return nullptr;
+        }
+    }
     return d;
 }
 
@@ -258,6 +283,41 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
         }
     }
     void *h = hidden_out;  // running hidden state, updated in place like decoder_output in the reference
+
+    // ---- fused fp16 decode path (batch <= 8): 5 launches per layer ----
+    //   qkv  = rmsnorm(h)*g1 . Wqkv^T                      (norm fused into the GEMV prologue)
+    //   mha  = attention(rope(q), rope(k) -> cache, v)     (RoPE + bias + KV append fused into the attention)
+    //   h   += mha . Wo^T                                   (residual epilogue; h is the residual stream)
+    //   act  = swiglu(rmsnorm(h + o.bias)*g2 . Wgu^T)      (norm prologue + SwiGLU epilogue)
+    //   h   += act . Wd^T
+    // Same math as self_decoder.cpp:69-119 (residual updated before the o.bias add, as the reference).
+    static const int fused_off = getenv("LLMIE_NO_FUSED_DECODE") ? 1 : 0;
+    const int rep = c.head_num / c.kv_head_num;
+    const bool hs_ok = c.head_size == 32 || c.head_size == 64 || c.head_size == 128 || c.head_size == 256;
+    const bool rep_ok = rep == 1 || rep == 2 || rep == 4 || rep == 8;
+    if (!fused_off && c.dtype == LLMIE_F16 && c.wfmt == LLMIE_W_F16 && hs_ok && rep_ok && H % 8 == 0 &&
+        gemv_f16_eligible(batch, H, h, dec->layers[0].qkv.data)) {
+        hipStream_t st = as_stream(stream);
+        for (int l = 0; l < c.num_layers; ++l) {
+            const llmie_layer_weights &w = dec->layers[l];
+            TIMED(LLMIE_OP_QKV_GEMM, linear_f16_nk_norm((const half_t *)h, (const half_t *)w.qkv.data, (half_t *)dec->qkv, batch, H,
+                                                        QKV, EPI_NONE_, nullptr, nullptr, (const half_t *)w.attn_norm_gamma,
+                                                        nullptr, c.rms_eps, st));
+            TIMED(LLMIE_OP_MHA, decoder_mha_rope(dec->qkv, w.qkv.bias, k_cache, v_cache, dec->mha, l, batch, c.head_num,
+                                                 c.kv_head_num, c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws,
+                                                 dec->attn_ws_bytes, dec->rope_table, c.rotary_dim, dt, st));
+            TIMED(LLMIE_OP_O_GEMM, linear_f16_nk((const half_t *)dec->mha, (const half_t *)w.o.data, (half_t *)h, batch, H, H,
+                                                 EPI_NONE_, nullptr, (const half_t *)h, st));
+            TIMED(LLMIE_OP_GATE_UP_SWIGLU, linear_f16_nk_norm((const half_t *)h, (const half_t *)w.gate_up.data, (half_t *)dec->act,
+                                                              batch, H, 2 * I, EPI_SWIGLU_, nullptr, nullptr,
+                                                              (const half_t *)w.ffn_norm_gamma, (const half_t *)w.o.bias,
+                                                              c.rms_eps, st));
+            TIMED(LLMIE_OP_DOWN_GEMM, linear_f16_nk((const half_t *)dec->act, (const half_t *)w.down.data, (half_t *)h, batch, I, H,
+                                                    EPI_NONE_, nullptr, (const half_t *)h, st));
+        }
+        return LLMIE_OK;
+    }
+
     for (int l = 0; l < c.num_layers; ++l) {
         const llmie_layer_weights &w = dec->layers[l];
         // self_decoder.cpp:77  resid = h ; h = rmsnorm(h)
@@ -295,11 +355,19 @@ extern "C" int llmie_lm_head_sample(llmie_decoder *dec, void *hidden, const void
     LLMIE_REQUIRE(batch >= 1 && batch <= c.max_batch, "lm_head_sample: batch %d outside [1,%d]", batch, c.max_batch);
     LLMIE_REQUIRE(c.vocab_size > 0, "lm_head_sample: vocab_size not set in the decoder config");
     int rc;
+    if (lm_fmt == LLMIE_W_F16 && c.dtype == LLMIE_F16 && gemv_f16_eligible(batch, dec->H, hidden, lm_head->data) &&
+        !getenv("LLMIE_NO_FUSED_DECODE")) {
+        // final RMSNorm fused into the LM-head GEMV prologue (hidden itself is left un-normalised)
+        TIMED(LLMIE_OP_LM_HEAD, linear_f16_nk_norm((const half_t *)hidden, (const half_t *)lm_head->data, (half_t *)logits, batch,
+                                                   dec->H, c.vocab_size, EPI_NONE_, (const half_t *)lm_head->bias, nullptr,
+                                                   (const half_t *)final_norm_gamma, nullptr, c.rms_eps, as_stream(stream)));
+    } else {
     // llama.cpp:247  final RMSNorm (the residual copy is unused there: pass NULL)
     TIMED(LLMIE_OP_FINAL_NORM, llmie_rmsnorm(hidden, nullptr, final_norm_gamma, c.rms_eps, batch, dec->H, c.dtype, stream));
     // llama.cpp:282  logits = hidden . lm_head^T
     TIMED(LLMIE_OP_LM_HEAD, engine_linear(dec, lm_fmt, hidden, *lm_head, logits, batch, dec->H, c.vocab_size, false, nullptr,
                                           false, stream));
+    }
     // llama.cpp:293,304
     TIMED(LLMIE_OP_TOPK, llmie_topk(logits, tmp_ids, tmp_vals, topk_ids, topk_vals, batch, c.vocab_size, K, blocks_per_row,
                                     c.dtype, stream));

@@ -1,9 +1,10 @@
 // Dense linear kernels for gfx950 behind llmie_linear / llmie_batched_gemm.
 //
-//   gemv_f16_kernel        M <= 8 tokens, fp16 W[N,K]: weight streaming, one wave per row pair,
-//                          16-byte non-temporal loads straight to VGPRs (no LDS round trip for the
-//                          stream), x staged once per workgroup in LDS, v_dot2_f32_f16 accumulate,
-//                          wave64 butterfly reduce.  HBM-bound: algorithmic bytes = N*K*2.
+//   gemv_ksplit_kernel     M <= 8 tokens, fp16 W[N,K]: weight streaming; a workgroup owns RPW rows and
+//                          splits K over its 256 threads, 16-byte non-temporal loads straight to VGPRs,
+//                          activation slice (and the fused RMSNorm) in registers, v_dot2_f32_f16, wave64
+//                          butterfly + one LDS exchange per iteration.  HBM-bound: bytes = N*K*2.
+//   gemv_lds_kernel        same contract for K outside the register budget (x staged in LDS).
 //   skinny_mfma_f16_kernel 1 <= M <= 64, fp16 W[N,K]: one 16-row weight tile per workgroup, the
 //                          waves split K, v_mfma_f32_16x16x32_f16 with W as the A operand (so the
 //                          weight fragment is one 16-byte load per lane) and x^T as B, LDS reduce
@@ -23,44 +24,217 @@ enum : int { EPI_NONE = 0, EPI_SWIGLU = 1 };
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------
-// GEMV: y[m, r] = sum_k x[m,k] * W[r,k]
-// grid: any (grid-stride over row pairs), block 256 (4 waves), dynamic LDS = M*K*2 bytes.
-// EPI_NONE  : pair p = rows (2p, 2p+1); y[M,N]
-// EPI_SWIGLU: pair p = rows (p, p+N/2); y[M,N/2] = silu(gate)*up
+// Decode GEMV family:  y[m, r] = sum_k xn[m,k] * W[r,k]   (fp16, M <= 8 tokens, W row-major [N,K])
+//   xn = x                                 (norm == 0)
+//   xn = rmsnorm(x + pre_bias) * gamma     (norm != 0: the RMSNorm in front of the projection is computed
+//        by every workgroup from the L2-resident activation row instead of by its own launch)
+// epi EPI_NONE  : y[M,N] (+bias[N]) (+residual[M,N], may alias y)
+// epi EPI_SWIGLU: y[M,N/2] = silu(gate) * up, rows (i, N/2+i) of a fused gate_up matrix
 // ------------------------------------------------------------------------------------------
-template <int M, int EPI, int U>
-__global__ __launch_bounds__(256) void gemv_f16_kernel(const half_t *__restrict__ x,
-                                                       const half_t *__restrict__ W,
-                                                       half_t *__restrict__ y, int K, int N,
-                                                       const half_t *__restrict__ bias,
-                                                       const half_t *__restrict__ residual) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    half8_t *xs = reinterpret_cast<half8_t *>(smem_raw);  // [M][K/8]
+struct GemvArgs {
+    const half_t *x;         // [M,K]
+    const half_t *W;         // [N,K]
+    half_t *y;
+    int K, N;
+    const half_t *bias;      // [N] or null (EPI_NONE)
+    const half_t *residual;  // [M,N] or null (EPI_NONE)
+    const half_t *gamma;     // [K]   (norm)
+    const half_t *pre_bias;  // [K] or null (norm)
+    float eps;
+    int epi, norm;
+};
+
+// K-split GEMV (the hot kernel).  One workgroup = 256 threads owns RPW rows per iteration and splits
+// K: thread t streams the 16-byte chunks t, t+256, ... of every row (a workgroup instruction covers
+// 4 KiB contiguous of one row), so the activation slice a thread needs is XC chunks and lives in
+// registers -- no LDS staging, no barrier in front of the stream; RPW*XC loads are in flight per lane.
+// The 4 waves meet once per iteration to add their partial sums through a double-buffered LDS slot.
+// Measured (tools/gemv_bench.hip, MI355X, incl. ~1 us launch gap): QKV 100.7 MB 16.7 us, O 33.6 MB
+// 7.6 us, down 90.2 MB 16.1 us, LM head 262 MB 42 us = 6.0 / 4.4 / 5.6 / 6.2 TB/s.
+template <int M, int RPW, int XC>
+__global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
+    static_assert(RPW % 2 == 0, "rows come in pairs");
+    __shared__ float red[2][4][M * RPW];
+    __shared__ float ssq[4][M];
+    const int K = a.K, N = a.N;
     const int nch = K >> 3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool swiglu = a.epi == EPI_SWIGLU;
+    const int half_n = N >> 1;
+    const int out_n = swiglu ? half_n : N;
+    // a group = RPW rows: EPI_NONE rows [g*RPW, g*RPW+RPW); SWIGLU RPW/2 gate rows + their up rows
+    const int ngroups = swiglu ? (half_n + RPW / 2 - 1) / (RPW / 2) : (N + RPW - 1) / RPW;
+    auto row_of = [&](int grp, int r) {
+        int row = swiglu ? grp * (RPW / 2) + (r >> 1) + (r & 1) * half_n : grp * RPW + r;
+        const int lim = swiglu ? ((r & 1) ? N : half_n) : N;
+        return row < lim ? row : lim - 1;  // clamp: result of a clamped row is never stored
+    };
+
+    // ---- activation slice of this thread (+ fused RMSNorm) ----
+    half8_t xr[M][XC];
+    const half8_t *xg = reinterpret_cast<const half8_t *>(a.x);
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int j = 0; j < XC; ++j) {
+            const int cc = j * 256 + tid;
+            xr[m][j] = cc < nch ? xg[m * nch + cc] : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    if (a.norm) {
+        const half8_t *pb = reinterpret_cast<const half8_t *>(a.pre_bias);
+        const half8_t *gm = reinterpret_cast<const half8_t *>(a.gamma);
+        half8_t g[XC];
+#pragma unroll
+        for (int j = 0; j < XC; ++j) {
+            const int cc = j * 256 + tid;
+            g[j] = cc < nch ? gm[cc] : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            if (pb && cc < nch) {
+                const half8_t b = pb[cc];
+#pragma unroll
+                for (int m = 0; m < M; ++m)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xr[m][j][e] = from_f32<half_t>(to_f32(xr[m][j][e]) + to_f32(b[e]));
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < XC; ++j) ss = dot8(xr[m][j], xr[m][j], ss);
+            ss = wave_sum(ss);
+            if (lane == 0) ssq[wave][m] = ss;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const float inv = rsqrtf((ssq[0][m] + ssq[1][m] + ssq[2][m] + ssq[3][m]) / static_cast<float>(K) + a.eps);
+#pragma unroll
+            for (int j = 0; j < XC; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xr[m][j][e] = from_f32<half_t>(to_f32(xr[m][j][e]) * to_f32(g[j][e]) * inv);
+        }
+    }
+
+    int it = 0;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x, ++it) {
+        half8_t wb[RPW][XC];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const half8_t *w = reinterpret_cast<const half8_t *>(a.W + static_cast<size_t>(row_of(grp, r)) * K);
+#pragma unroll
+            for (int j = 0; j < XC; ++j) {
+                const int cc = j * 256 + tid;
+                wb[r][j] = cc < nch ? load_nt(w + cc) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+        float acc[M][RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < XC; ++j) s = dot8(wb[r][j], xr[m][j], s);
+                acc[m][r] = wave_sum(s);
+            }
+        float *slot = &red[it & 1][0][0];
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < M; ++m)
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) slot[wave * (M * RPW) + m * RPW + r] = acc[m][r];
+        }
+        __syncthreads();  // one barrier per iteration: the other parity slot is free for the next iteration
+        if (swiglu) {
+            if (tid < M * (RPW / 2)) {
+                const int m = tid / (RPW / 2), q = tid % (RPW / 2);
+                const int col = grp * (RPW / 2) + q;
+                if (col < half_n) {
+                    float gt = 0.f, up = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        gt += slot[w * (M * RPW) + m * RPW + 2 * q];
+                        up += slot[w * (M * RPW) + m * RPW + 2 * q + 1];
+                    }
+                    a.y[static_cast<size_t>(m) * out_n + col] = from_f32<half_t>((gt / (1.0f + expf(-gt))) * up);
+                }
+            }
+        } else {
+            if (tid < M * RPW) {
+                const int m = tid / RPW, r = tid % RPW;
+                const int col = grp * RPW + r;
+                if (col < N) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) v += slot[w * (M * RPW) + m * RPW + r];
+                    if (a.bias) v += to_f32(a.bias[col]);
+                    if (a.residual) v += to_f32(a.residual[static_cast<size_t>(m) * N + col]);
+                    a.y[static_cast<size_t>(m) * N + col] = from_f32<half_t>(v);
+                }
+            }
+        }
+    }
+}
+
+// Fallback for K outside the K-split kernel's register budget (any K % 8 == 0 with M*K*2 <= 64 KB):
+// x staged once per workgroup in LDS, one wave per row pair, 16 loads single shot.
+template <int M>
+__global__ __launch_bounds__(256) void gemv_lds_kernel(const GemvArgs a) {
+    constexpr int U = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    half8_t *xs = reinterpret_cast<half8_t *>(smem_raw);  // [M][K/8]
+    __shared__ float inv_rms[M];
+    const int K = a.K, N = a.N;
+    const int nch = K >> 3, total = M * nch;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool swiglu = a.epi == EPI_SWIGLU;
     {
-        const half8_t *xg = reinterpret_cast<const half8_t *>(x);
-        for (int i = tid; i < M * nch; i += 256) xs[i] = xg[i];
+        const half8_t *xg = reinterpret_cast<const half8_t *>(a.x);
+        const half8_t *pb = reinterpret_cast<const half8_t *>(a.pre_bias);
+        for (int i = tid; i < total; i += 256) {
+            half8_t v = xg[i];
+            if (a.norm && pb) {
+                const half8_t b = pb[i % nch];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = from_f32<half_t>(to_f32(v[e]) + to_f32(b[e]));
+            }
+            xs[i] = v;
+        }
     }
     __syncthreads();
-
-    const int half_n = N >> 1;
-    const int npairs = (EPI == EPI_SWIGLU) ? half_n : ((N + 1) >> 1);
-    for (int pair = blockIdx.x * 4 + wave; pair < npairs; pair += gridDim.x * 4) {
-        int r0, r1;
-        if constexpr (EPI == EPI_SWIGLU) {
-            r0 = pair;
-            r1 = pair + half_n;
-        } else {
-            r0 = 2 * pair;
-            r1 = min(2 * pair + 1, N - 1);  // odd N: duplicate the last row, result discarded
+    if (a.norm) {
+        for (int m = wave; m < M; m += 4) {
+            float ss = 0.f;
+            for (int c = lane; c < nch; c += 64) {
+                const half8_t v = xs[m * nch + c];
+                ss = dot8(v, v, ss);
+            }
+            ss = wave_sum(ss);
+            if (lane == 0) inv_rms[m] = rsqrtf(ss / static_cast<float>(K) + a.eps);
         }
-        const half8_t *w0 = reinterpret_cast<const half8_t *>(W + static_cast<size_t>(r0) * K);
-        const half8_t *w1 = reinterpret_cast<const half8_t *>(W + static_cast<size_t>(r1) * K);
+        __syncthreads();
+        const half8_t *gm = reinterpret_cast<const half8_t *>(a.gamma);
+        for (int i = tid; i < total; i += 256) {
+            const int m = i / nch, c = i - m * nch;
+            half8_t v = xs[i];
+            const half8_t g = gm[c];
+            const float sc = inv_rms[m];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = from_f32<half_t>(to_f32(v[e]) * to_f32(g[e]) * sc);
+            xs[i] = v;
+        }
+        __syncthreads();
+    }
+    const int half_n = N >> 1;
+    const int npairs = swiglu ? half_n : ((N + 1) >> 1);
+    for (int pair = blockIdx.x * 4 + wave; pair < npairs; pair += gridDim.x * 4) {
+        const int r0 = swiglu ? pair : 2 * pair;
+        const int r1 = swiglu ? pair + half_n : min(2 * pair + 1, N - 1);  // odd N: duplicate row, result discarded
+        const half8_t *w0 = reinterpret_cast<const half8_t *>(a.W + static_cast<size_t>(r0) * K);
+        const half8_t *w1 = reinterpret_cast<const half8_t *>(a.W + static_cast<size_t>(r1) * K);
         float acc0[M], acc1[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) acc0[m] = acc1[m] = 0.f;
-
         for (int c = lane; c < nch; c += 64 * U) {
             half8_t a0[U], a1[U];
 #pragma unroll
@@ -92,21 +266,22 @@ __global__ __launch_bounds__(256) void gemv_f16_kernel(const half_t *__restrict_
         if (lane == 0) {
 #pragma unroll
             for (int m = 0; m < M; ++m) {
-                if constexpr (EPI == EPI_SWIGLU) {
-                    const float g = acc0[m], u = acc1[m];
-                    y[static_cast<size_t>(m) * half_n + pair] = from_f32<half_t>((g / (1.0f + expf(-g))) * u);
+                if (swiglu) {
+                    const float gt = acc0[m], up = acc1[m];
+                    a.y[static_cast<size_t>(m) * half_n + pair] = from_f32<half_t>((gt / (1.0f + expf(-gt))) * up);
                 } else {
                     float v0 = acc0[m], v1 = acc1[m];
-                    if (bias) {
-                        v0 += to_f32(bias[r0]);
-                        v1 += to_f32(bias[r1]);
+                    const bool has1 = 2 * pair + 1 < N;
+                    if (a.bias) {
+                        v0 += to_f32(a.bias[r0]);
+                        v1 += to_f32(a.bias[r1]);
                     }
-                    if (residual) {
-                        v0 += to_f32(residual[static_cast<size_t>(m) * N + r0]);
-                        if (2 * pair + 1 < N) v1 += to_f32(residual[static_cast<size_t>(m) * N + r1]);
+                    if (a.residual) {
+                        v0 += to_f32(a.residual[static_cast<size_t>(m) * N + r0]);
+                        if (has1) v1 += to_f32(a.residual[static_cast<size_t>(m) * N + r1]);
                     }
-                    y[static_cast<size_t>(m) * N + r0] = from_f32<half_t>(v0);
-                    if (2 * pair + 1 < N) y[static_cast<size_t>(m) * N + r1] = from_f32<half_t>(v1);
+                    a.y[static_cast<size_t>(m) * N + r0] = from_f32<half_t>(v0);
+                    if (has1) a.y[static_cast<size_t>(m) * N + r1] = from_f32<half_t>(v1);
                 }
             }
         }

@@ -17,29 +17,54 @@ static int decode_gemm_mode() {
     return mode;
 }
 
-template <int M, int EPI>
-static void launch_gemv(const half_t *x, const half_t *W, half_t *y, int K, int N, const half_t *bias,
-                        const half_t *residual, hipStream_t st) {
-    const int npairs = (EPI == EPI_SWIGLU) ? N / 2 : (N + 1) / 2;
-    int wgs = (npairs + 3) / 4;
-    // >= 2 workgroups per CU when there is enough work, at most 8 per CU (grid-stride beyond)
-    if (wgs > 2048) wgs = 2048;
-    const size_t lds = static_cast<size_t>(M) * K * sizeof(half_t);
-    gemv_f16_kernel<M, EPI, 8><<<wgs, 256, lds, st>>>(x, W, y, K, N, bias, residual);
+// ---- decode GEMV dispatch ----
+// K-split kernel: XC = chunks per thread = ceil(K/8/256) rounded up to {1,2,4,6,8}; RPW rows per iteration so
+// that RPW*XC ~ 16 loads are in flight per lane; register budget M*XC <= 16.
+template <int M, int RPW, int XC> static void launch_ksplit(const GemvArgs &a, hipStream_t st) {
+    const bool swiglu = a.epi == EPI_SWIGLU;
+    const int groups = swiglu ? (a.N / 2 + RPW / 2 - 1) / (RPW / 2) : (a.N + RPW - 1) / RPW;
+    // long-lived workgroups (the prologue -- activation slice + norm -- is paid once per workgroup), evenly loaded
+    static const int target = env_int("LLMIE_GEMV_TARGET_WGS", 768);
+    const int iters = (groups + target - 1) / target;
+    const int grid = (groups + iters - 1) / iters;
+    gemv_ksplit_kernel<M, RPW, XC><<<grid, 256, 0, st>>>(a);
 }
 
-template <int EPI>
-static bool dispatch_gemv(int M, const half_t *x, const half_t *W, half_t *y, int K, int N,
-                          const half_t *bias, const half_t *residual, hipStream_t st) {
+template <int M> static bool dispatch_ksplit(const GemvArgs &a, hipStream_t st) {
+    const int xc = (a.K / 8 + 255) / 256;
+    if (xc <= 1) { launch_ksplit<M, 8, 1>(a, st); return true; }
+    if (xc <= 2) { launch_ksplit<M, 8, 2>(a, st); return true; }
+    if constexpr (M <= 4) {
+        if (xc <= 4) { launch_ksplit<M, 4, 4>(a, st); return true; }
+    }
+    if constexpr (M <= 2) {
+        if (xc <= 6) { launch_ksplit<M, 4, 6>(a, st); return true; }
+        if (xc <= 8) { launch_ksplit<M, 2, 8>(a, st); return true; }
+    }
+    return false;
+}
+
+template <int M> static bool dispatch_gemv_m(const GemvArgs &a, hipStream_t st) {
+    if (dispatch_ksplit<M>(a, st)) return true;
+    if (static_cast<size_t>(M) * a.K * 2 > 64 * 1024) return false;
+    const bool swiglu = a.epi == EPI_SWIGLU;
+    const int npairs = swiglu ? a.N / 2 : (a.N + 1) / 2;
+    int wgs = (npairs + 3) / 4;
+    if (wgs > 2048) wgs = 2048;
+    gemv_lds_kernel<M><<<wgs, 256, static_cast<size_t>(M) * a.K * sizeof(half_t), st>>>(a);
+    return true;
+}
+
+static bool dispatch_gemv(int M, const GemvArgs &a, hipStream_t st) {
     switch (M) {
-        case 1: launch_gemv<1, EPI>(x, W, y, K, N, bias, residual, st); return true;
-        case 2: launch_gemv<2, EPI>(x, W, y, K, N, bias, residual, st); return true;
-        case 3: launch_gemv<3, EPI>(x, W, y, K, N, bias, residual, st); return true;
-        case 4: launch_gemv<4, EPI>(x, W, y, K, N, bias, residual, st); return true;
-        case 5: launch_gemv<5, EPI>(x, W, y, K, N, bias, residual, st); return true;
-        case 6: launch_gemv<6, EPI>(x, W, y, K, N, bias, residual, st); return true;
-        case 7: launch_gemv<7, EPI>(x, W, y, K, N, bias, residual, st); return true;
-        case 8: launch_gemv<8, EPI>(x, W, y, K, N, bias, residual, st); return true;
+        case 1: return dispatch_gemv_m<1>(a, st);
+        case 2: return dispatch_gemv_m<2>(a, st);
+        case 3: return dispatch_gemv_m<3>(a, st);
+        case 4: return dispatch_gemv_m<4>(a, st);
+        case 5: return dispatch_gemv_m<5>(a, st);
+        case 6: return dispatch_gemv_m<6>(a, st);
+        case 7: return dispatch_gemv_m<7>(a, st);
+        case 8: return dispatch_gemv_m<8>(a, st);
         default: return false;
     }
 }
@@ -81,15 +106,38 @@ static void launch_generic(const T *a, const T *b, T *c, int batch, int M, int N
         generic_gemm_kernel<T, false><<<grid, 256, 0, st>>>(a, b, c, M, N, K, sa, sb, sc, bias, residual);
 }
 
-// fp16, W[N,K]: the decode / prefill projection path.  epi selects the fused epilogue.
+// fp16, W[N,K]: the decode / prefill projection path.  epi selects the fused epilogue; a non-null
+// `norm` fuses rmsnorm(x + pre_bias)*gamma in front of the projection (GEMV path only: returns
+// LLMIE_ERR_UNSUPPORTED otherwise so the caller can run the norm as its own kernel).
+// does the GEMV family take (M, K)?  (K-split register budget, else the LDS fallback's 64 KB)
+bool gemv_f16_eligible(int M, int K, const void *x, const void *W) {
+    if (K % 8 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) % 16) || M < 1 || M > 8 ||
+        decode_gemm_mode() == 2)
+        return false;
+    const int xc = (K / 8 + 255) / 256;
+    const bool ksplit = xc <= 2 || (M <= 4 && xc <= 4) || (M <= 2 && xc <= 8);
+    return ksplit || static_cast<size_t>(M) * K * 2 <= 64 * 1024;
+}
+
+int linear_f16_nk_norm(const half_t *x, const half_t *W, half_t *y, int M, int K, int N, int epi, const half_t *bias,
+                       const half_t *residual, const half_t *gamma, const half_t *pre_bias, float eps, hipStream_t st) {
+    if (!gemv_f16_eligible(M, K, x, W) || !gamma || reinterpret_cast<uintptr_t>(gamma) % 16 ||
+        reinterpret_cast<uintptr_t>(pre_bias) % 16) {
+        set_error("linear(norm-fused): shape M=%d K=%d not on the GEMV path", M, K);
+        return LLMIE_ERR_UNSUPPORTED;
+    }
+    const GemvArgs a{x, W, y, K, N, bias, residual, gamma, pre_bias, eps, epi, 1};
+    dispatch_gemv(M, a, st);
+    return launch_status("linear(norm-fused)");
+}
+
 int linear_f16_nk(const half_t *x, const half_t *W, half_t *y, int M, int K, int N, int epi,
                   const half_t *bias, const half_t *residual, hipStream_t st) {
     const bool aligned = (K % 8 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) % 16 == 0);
-    const int mode = decode_gemm_mode();
     bool done = false;
-    if (aligned && M <= 8 && mode != 2 && static_cast<size_t>(M) * K * 2 <= 64 * 1024) {
-        done = (epi == EPI_SWIGLU) ? dispatch_gemv<EPI_SWIGLU>(M, x, W, y, K, N, bias, residual, st)
-                                   : dispatch_gemv<EPI_NONE>(M, x, W, y, K, N, bias, residual, st);
+    if (gemv_f16_eligible(M, K, x, W)) {
+        const GemvArgs a{x, W, y, K, N, bias, residual, nullptr, nullptr, 0.f, epi, 0};
+        done = dispatch_gemv(M, a, st);
     }
     if (!done && aligned && M <= 64 && K % 32 == 0 && (epi != EPI_SWIGLU || (N / 2) % 16 == 0)) {
         done = (epi == EPI_SWIGLU) ? dispatch_skinny<EPI_SWIGLU>(M, x, W, y, K, N, bias, residual, st)
