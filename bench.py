@@ -253,7 +253,7 @@ def main():
     gu_ms, gu_n = prof["gate_up_swiglu"]
     gu_us = gu_ms / gu_n * 1e3
     achieved = gu_bytes / (gu_us * 1e-6) / 1e9
-    roofline = dict(bound="hbm", kernel="gemv_f16_kernel<M=%d, SWIGLU> (gate/up projection + SwiGLU)" % B,
+    roofline = dict(bound="hbm", kernel="gemv_ksplit_kernel<M=%d,RPW=8,XC=2> (RMSNorm + gate/up projection + SwiGLU)" % B,
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
                     algorithmic_bytes_per_launch=gu_bytes, us_per_launch=round(gu_us, 2), launches_timed=gu_n)

@@ -138,6 +138,19 @@ int llmie_decoder_mha(const void *qkv, const void *qkv_bias, void *k_cache, void
                       void *workspace, size_t workspace_bytes,
                       llmie_dtype dtype, llmie_stream stream);
 
+/* Fused form used by the decoder engine: launchRope + launchDecoderMaskedMultiHeadAttention in one launch
+ * (src/layers/self_attention.cpp:100-118).  rope_table: [max_pos][head_size/2] pairs (cos, sin) of
+ * pos / base^(2j/rot_dim) (NULL = q,k already rotated); q and the new k are rotated in-kernel before the
+ * bias add, exactly the reference's order.  tickets: [batch, kv_head_num] int32 arrival counters that must be
+ * ZERO before the first call (the kernel re-arms them): the last workgroup of each (batch, kv head) merges the
+ * split partials in the same launch (no merge kernel).  NULL tickets = separate merge kernel.
+ * Supported: head_size in {32,64,128,256}, head_num/kv_head_num in {1,2,4,8}; else LLMIE_ERR_UNSUPPORTED. */
+int llmie_decoder_mha_rope(const void *qkv, const void *qkv_bias, void *k_cache, void *v_cache,
+                           void *out, int layer, int batch, int head_num, int kv_head_num,
+                           int head_size, int max_seq_len, int step, const int32_t *step_dev,
+                           void *workspace, size_t workspace_bytes, const void *rope_table,
+                           int rotary_dim, int32_t *tickets, llmie_dtype dtype, llmie_stream stream);
+
 /* replaces launchConcatKVCache         src/kernels/concat_past_kv.cu:44-89  (one call = K or V) */
 int llmie_concat_kv(const void *src, void *cache, const int32_t *cur_len,
                     const int32_t *history_len, int layer, int batch, int kv_head_num,

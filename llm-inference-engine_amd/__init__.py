@@ -51,6 +51,8 @@ _SIGS = {
     "llmie_rope_decode": [_vp, _i, _i, _i, _i, _i, _vp, _i, _f, _i, _vp],
     "llmie_decoder_mha_workspace_bytes": [_i, _i, _i, _i],
     "llmie_decoder_mha": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp],
+    "llmie_decoder_mha_rope": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _i, _vp, _i,
+                               _vp],
     "llmie_concat_kv": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "llmie_repeat_kv": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "llmie_scale_mask_softmax": [_vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp],
@@ -217,6 +219,16 @@ def decoder_mha(qkv, qkv_bias, k_cache, v_cache, out, layer, head_num, kv_head_n
                                    kv_head_num, hs, max_seq, step, _p(step_dev), _p(workspace),
                                    0 if workspace is None else workspace.numel() * workspace.element_size(),
                                    _dt(qkv), _st()), "decoder_mha")
+    return out
+
+
+def decoder_mha_rope(qkv, qkv_bias, k_cache, v_cache, out, layer, head_num, kv_head_num, step, workspace, rope_table,
+                     rotary_dim, tickets, step_dev=None):
+    bs, _, hs = qkv.shape
+    _check(lib().llmie_decoder_mha_rope(_p(qkv), _p(qkv_bias), _p(k_cache), _p(v_cache), _p(out), layer, bs, head_num,
+                                        kv_head_num, hs, k_cache.shape[3], step, _p(step_dev), _p(workspace),
+                                        workspace.numel() * workspace.element_size(), _p(rope_table), rotary_dim,
+                                        _p(tickets), _dt(qkv), _st()), "decoder_mha_rope")
     return out
 
 

@@ -29,12 +29,46 @@ template <typename T, int HS> struct AttnGeom {
 
 __host__ __device__ inline int attn_min_chunk() { return 32; }
 
+// Merge of the per-split (m, l, o[d]) partials of one (batch, head) for output dim d: 16 splits per round,
+// every load of a round issued before the first use.  Shared by the stand-alone merge kernel and by the
+// in-kernel merge of the last-arriving workgroup, so both give bit-identical results.
+__device__ __forceinline__ float merge_splits(const float *__restrict__ p, int nsplits, size_t stride, int d) {
+    float M = -INFINITY, L = 0.f, o = 0.f;
+    for (int s0 = 0; s0 < nsplits; s0 += 16) {
+        float ms[16], ls[16], os[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int s = min(s0 + i, nsplits - 1);
+            ms[i] = p[s * stride];
+            ls[i] = p[s * stride + 1];
+            os[i] = p[s * stride + 2 + d];
+        }
+        float Mc = M;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (s0 + i < nsplits) Mc = fmaxf(Mc, ms[i]);
+        const float rescale = (M == -INFINITY) ? 0.f : __expf(M - Mc);
+        L *= rescale;
+        o *= rescale;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (s0 + i < nsplits) {
+                const float f = __expf(ms[i] - Mc);
+                L = fmaf(f, ls[i], L);
+                o = fmaf(f, os[i], o);
+            }
+        M = Mc;
+    }
+    return o / (L + 1e-6f);
+}
+
 template <typename T, int HS, int REP>
 __global__ __launch_bounds__(256) void decode_attn_split_kernel(
     const T *__restrict__ qkv, const T *__restrict__ qkv_bias, T *k_cache, T *v_cache,
     float *__restrict__ part, T *__restrict__ out, int head_num, int kv_head_num, int max_seq_len,
     int step_arg, const int32_t *__restrict__ step_dev, int max_splits,
-    const float2 *__restrict__ rope /* [max_pos][HS/2] (cos,sin) or null */, int rotary_dim) {
+    const float2 *__restrict__ rope /* [max_pos][HS/2] (cos,sin) or null */, int rotary_dim,
+    int32_t *tickets /* [batch, kv_head_num] zero-initialised arrival counters, or null = separate merge kernel */) {
     using G = AttnGeom<T, HS>;
     using V = typename Vec16<T>::type;
     constexpr int N = G::N, LPT = G::LPT, TPW = G::TPW, CHUNK = G::CHUNK;
@@ -55,16 +89,43 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
 
     const T *row = qkv + static_cast<size_t>(b) * qkv_heads * HS;
     // q for the REP heads of this kv head, pre-scaled, fp32
-    // RoPE (fused form of launchRope, rope.cu:4-43): rotate-half pairs (d, d+HS/2) live LPT/2 lanes apart
+    const size_t head_off = (static_cast<size_t>(b) * kv_head_num + g) * max_seq_len * HS;
+    T *kc = k_cache + head_off;
+    T *vc = v_cache + head_off;
     const int t_new = step - 1;
-    const bool rope_first = dl < LPT / 2;
-    float rc[N], rs[N];
+    // small L2-resident operands first (q rows, RoPE row), then the K/V stream; q is processed after the K/V
+    // loads have been issued, so its latency hides under theirs (vmcnt retires in order: q is older)
+    V qraw[REP];
+#pragma unroll
+    for (int r = 0; r < REP; ++r) qraw[r] = reinterpret_cast<const V *>(row + static_cast<size_t>(g * REP + r) * HS)[dl];
+    float2 csraw[N];
     if (rope) {
         const float2 *cs = rope + static_cast<size_t>(t_new) * (HS / 2) + (dl % (LPT / 2)) * N;
 #pragma unroll
+        for (int e = 0; e < N; ++e) csraw[e] = cs[e];
+    }
+    // ---- issue every K and V load of this wave's token range ----
+    V kv[kAttnG], vv[kAttnG];
+    int tok[kAttnG];
+#pragma unroll
+    for (int i = 0; i < kAttnG; ++i) {
+        const int t = t0 + (wave * kAttnG + i) * TPW + sub;
+        tok[i] = t;
+        if (t < t_end && t != t_new) kv[i] = load_nt(reinterpret_cast<const V *>(kc + static_cast<size_t>(t) * HS) + dl);
+    }
+#pragma unroll
+    for (int i = 0; i < kAttnG; ++i) {
+        const int t = tok[i];
+        if (t < t_end && t != t_new) vv[i] = load_nt(reinterpret_cast<const V *>(vc + static_cast<size_t>(t) * HS) + dl);
+    }
+    // RoPE (fused form of launchRope, rope.cu:4-43): rotate-half pairs (d, d+HS/2) live LPT/2 lanes apart
+    const bool rope_first = dl < LPT / 2;
+    float rc[N], rs[N];
+    if (rope) {
+#pragma unroll
         for (int e = 0; e < N; ++e) {
             const bool rot = ((dl % (LPT / 2)) * N + e) < (rotary_dim >> 1);
-            const float2 v = rot ? cs[e] : float2{1.f, 0.f};
+            const float2 v = rot ? csraw[e] : float2{1.f, 0.f};
             rc[e] = v.x;
             rs[e] = rope_first ? -v.y : v.y;
         }
@@ -80,7 +141,7 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
 #pragma unroll
     for (int r = 0; r < REP; ++r) {
         const int h = g * REP + r;
-        V qv = reinterpret_cast<const V *>(row + static_cast<size_t>(h) * HS)[dl];
+        const V qv = qraw[r];
         float f[N];
 #pragma unroll
         for (int e = 0; e < N; ++e) f[e] = to_f32(qv[e]);
@@ -95,24 +156,7 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
             qf[r][e] = f[e] * scale;
         }
     }
-    const size_t head_off = (static_cast<size_t>(b) * kv_head_num + g) * max_seq_len * HS;
-    T *kc = k_cache + head_off;
-    T *vc = v_cache + head_off;
 
-    // ---- issue every K and V load of this wave's token range ----
-    V kv[kAttnG], vv[kAttnG];
-    int tok[kAttnG];
-#pragma unroll
-    for (int i = 0; i < kAttnG; ++i) {
-        const int t = t0 + (wave * kAttnG + i) * TPW + sub;
-        tok[i] = t;
-        if (t < t_end && t != t_new) kv[i] = load_nt(reinterpret_cast<const V *>(kc + static_cast<size_t>(t) * HS) + dl);
-    }
-#pragma unroll
-    for (int i = 0; i < kAttnG; ++i) {
-        const int t = tok[i];
-        if (t < t_end && t != t_new) vv[i] = load_nt(reinterpret_cast<const V *>(vc + static_cast<size_t>(t) * HS) + dl);
-    }
     // the token of this step comes from the qkv buffer (+bias) and is appended to the cache
 #pragma unroll
     for (int i = 0; i < kAttnG; ++i) {
@@ -239,42 +283,56 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
         }
     }
     (void)batch;
+    // ---- in-launch merge by the last-arriving workgroup of this (batch, kv head) ----
+    // Placement-independent hand-off (cdna_hip_programming.md Guideline 16, counter form): plain partial stores ->
+    // every storing wave drains vmcnt -> workgroup barrier -> lane 0: agent-scope release, drained, then ONE relaxed
+    // agent-scope ticket -> the workgroup that draws nsplits-1 acquires (agent scope), barrier, reads all partials.
+    if (tickets && nsplits > 1) {
+        __shared__ int s_ticket;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int32_t *cnt = tickets + static_cast<size_t>(b) * kv_head_num + g;
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (s_ticket == nsplits - 1) {  // workgroup-uniform
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
+            }
+            __syncthreads();
+            const size_t stride = static_cast<size_t>(HS) + 2;
+            for (int i = threadIdx.x; i < REP * HS; i += 256) {
+                const int r = i / HS, d = i - r * HS;
+                const int h = g * REP + r;
+                const float *p = part + (static_cast<size_t>(b) * head_num + h) * max_splits * stride;
+                out[(static_cast<size_t>(b) * head_num + h) * HS + d] = from_f32<T>(merge_splits(p, nsplits, stride, d));
+            }
+        }
+    }
 }
 
-// merge the per-split partials: grid (head_num, batch), 128 threads.  Split weights are computed once
-// in parallel (lane per split) and kept in LDS; the hs outputs then accumulate over the splits with all
-// loads independent, so the kernel costs about one L2 round trip.
+// merge the per-split partials: grid (head_num, batch), one thread per output dim.  Every thread reads the
+// (m, l) pairs itself (broadcast loads) and its own o values, 16 splits per round with all loads issued before
+// the first use, so the kernel is about one L2 round trip per 16 splits -- no LDS, no barrier.
 template <typename T>
-__global__ __launch_bounds__(128) void decode_attn_combine_kernel(const float *__restrict__ part,
+__global__ __launch_bounds__(256) void decode_attn_combine_kernel(const float *__restrict__ part,
                                                                   T *__restrict__ out, int head_num,
                                                                   int head_size, int chunk, int step_arg,
                                                                   const int32_t *__restrict__ step_dev,
                                                                   int max_splits) {
-    extern __shared__ float w_s[];  // [nsplits] un-normalised split weights
-    __shared__ float red[2];
     const int step = step_dev ? *step_dev : step_arg;
     const int nsplits = (step + chunk - 1) / chunk;
     if (nsplits <= 1) return;  // the split kernel already wrote the final output
     const int h = blockIdx.x, b = blockIdx.y;
     const size_t stride = static_cast<size_t>(head_size) + 2;
     const float *p = part + (static_cast<size_t>(b) * head_num + h) * max_splits * stride;
-    float m_loc = -INFINITY;
-    for (int s = threadIdx.x; s < nsplits; s += 128) m_loc = fmaxf(m_loc, p[s * stride]);
-    const float M = block_max<2>(m_loc, red);
-    float l_loc = 0.f;
-    for (int s = threadIdx.x; s < nsplits; s += 128) {
-        const float f = __expf(p[s * stride] - M);
-        w_s[s] = f;
-        l_loc += f * p[s * stride + 1];
-    }
-    const float L = block_sum<2>(l_loc, red);  // contains the barrier that publishes w_s
-    const float inv = 1.0f / (L + 1e-6f);
-    for (int d = threadIdx.x; d < head_size; d += 128) {
-        float o = 0.f;
-#pragma unroll 8
-        for (int s = 0; s < nsplits; ++s) o = fmaf(w_s[s], p[s * stride + 2 + d], o);
-        out[(static_cast<size_t>(b) * head_num + h) * head_size + d] = from_f32<T>(o * inv);
-    }
+    for (int d = threadIdx.x; d < head_size; d += blockDim.x)
+        out[(static_cast<size_t>(b) * head_num + h) * head_size + d] = from_f32<T>(merge_splits(p, nsplits, stride, d));
 }
 
 // Any head size / GQA ratio (e.g. the reference unit test's hs=4): one workgroup per (b, q-head),
@@ -338,30 +396,30 @@ __global__ __launch_bounds__(256) void decode_attn_generic_kernel(
 template <typename T, int HS, int REP>
 static void launch_split(const T *qkv, const T *bias, T *kc, T *vc, float *part, T *out, int batch,
                          int head_num, int kv_head_num, int max_seq_len, int step, const int32_t *step_dev,
-                         int max_splits_ws, const float2 *rope, int rot_dim, hipStream_t st) {
+                         int max_splits_ws, const float2 *rope, int rot_dim, int32_t *tickets, hipStream_t st) {
     constexpr int CHUNK = AttnGeom<T, HS>::CHUNK;
     const int bound = step_dev ? max_seq_len : step;
     const int splits = (bound + CHUNK - 1) / CHUNK;
     dim3 grid(splits, kv_head_num, batch);
     decode_attn_split_kernel<T, HS, REP><<<grid, 256, 0, st>>>(qkv, bias, kc, vc, part, out, head_num,
                                                                kv_head_num, max_seq_len, step, step_dev, max_splits_ws,
-                                                               rope, rot_dim);
-    if (splits > 1) {
+                                                               rope, rot_dim, tickets);
+    if (splits > 1 && !tickets) {
         dim3 cgrid(head_num, batch);
-        decode_attn_combine_kernel<T><<<cgrid, 128, sizeof(float) * splits, st>>>(part, out, head_num, HS, CHUNK, step,
-                                                                                 step_dev, max_splits_ws);
+        decode_attn_combine_kernel<T><<<cgrid, HS < 64 ? 64 : (HS > 256 ? 256 : HS), 0, st>>>(part, out, head_num, HS, CHUNK,
+                                                                                              step, step_dev, max_splits_ws);
     }
 }
 
 template <typename T, int HS>
 static bool dispatch_rep(int rep, const T *qkv, const T *bias, T *kc, T *vc, float *part, T *out, int batch,
                          int head_num, int kv_head_num, int max_seq_len, int step, const int32_t *step_dev,
-                         int max_splits_ws, const float2 *rope, int rot_dim, hipStream_t st) {
+                         int max_splits_ws, const float2 *rope, int rot_dim, int32_t *tickets, hipStream_t st) {
     switch (rep) {
-        case 1: launch_split<T, HS, 1>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, st); return true;
-        case 2: launch_split<T, HS, 2>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, st); return true;
-        case 4: launch_split<T, HS, 4>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, st); return true;
-        case 8: launch_split<T, HS, 8>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, st); return true;
+        case 1: launch_split<T, HS, 1>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, st); return true;
+        case 2: launch_split<T, HS, 2>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, st); return true;
+        case 4: launch_split<T, HS, 4>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, st); return true;
+        case 8: launch_split<T, HS, 8>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, st); return true;
         default: return false;
     }
 }
@@ -370,7 +428,7 @@ template <typename T>
 static int decoder_mha_impl(const T *qkv, const T *bias, T *k_cache, T *v_cache, T *out, int layer, int batch,
                             int head_num, int kv_head_num, int head_size, int max_seq_len, int step,
                             const int32_t *step_dev, void *workspace, size_t workspace_bytes, const float2 *rope,
-                            int rot_dim, hipStream_t st) {
+                            int rot_dim, int32_t *tickets, hipStream_t st) {
     const size_t layer_off = static_cast<size_t>(layer) * batch * kv_head_num * max_seq_len * head_size;
     T *kc = k_cache + layer_off, *vc = v_cache + layer_off;
     const int rep = head_num / kv_head_num;
@@ -383,13 +441,13 @@ static int decoder_mha_impl(const T *qkv, const T *bias, T *k_cache, T *v_cache,
         float *part = static_cast<float *>(workspace);
         auto ws_ok = [&]() { return workspace && workspace_bytes >= need; };
         if (head_size == 128 && ws_ok())
-            done = dispatch_rep<T, 128>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, st);
+            done = dispatch_rep<T, 128>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, st);
         else if (head_size == 64 && ws_ok())
-            done = dispatch_rep<T, 64>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, st);
+            done = dispatch_rep<T, 64>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, st);
         else if (head_size == 32 && ws_ok())
-            done = dispatch_rep<T, 32>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, st);
+            done = dispatch_rep<T, 32>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, st);
         else if (head_size == 256 && ws_ok())
-            done = dispatch_rep<T, 256>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, st);
+            done = dispatch_rep<T, 256>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, st);
         if (!done && (head_size == 128 || head_size == 64 || head_size == 32 || head_size == 256) && !ws_ok() &&
             (rep == 1 || rep == 2 || rep == 4 || rep == 8)) {
             set_error("decoder_mha: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
@@ -417,15 +475,15 @@ static int decoder_mha_impl(const T *qkv, const T *bias, T *k_cache, T *v_cache,
 // engine entry: same as llmie_decoder_mha with RoPE (table [max_pos][hs/2] of (cos,sin)) fused in front
 int decoder_mha_rope(const void *qkv, const void *qkv_bias, void *k_cache, void *v_cache, void *out, int layer, int batch,
                      int head_num, int kv_head_num, int head_size, int max_seq_len, int step, const int32_t *step_dev,
-                     void *workspace, size_t workspace_bytes, const float2 *rope, int rot_dim, llmie_dtype dtype,
-                     hipStream_t st) {
+                     void *workspace, size_t workspace_bytes, const float2 *rope, int rot_dim, int32_t *tickets,
+                     llmie_dtype dtype, hipStream_t st) {
     if (dtype == LLMIE_F32)
         return decoder_mha_impl<float>((const float *)qkv, (const float *)qkv_bias, (float *)k_cache, (float *)v_cache,
                                        (float *)out, layer, batch, head_num, kv_head_num, head_size, max_seq_len, step,
-                                       step_dev, workspace, workspace_bytes, rope, rot_dim, st);
+                                       step_dev, workspace, workspace_bytes, rope, rot_dim, tickets, st);
     return decoder_mha_impl<half_t>((const half_t *)qkv, (const half_t *)qkv_bias, (half_t *)k_cache, (half_t *)v_cache,
                                     (half_t *)out, layer, batch, head_num, kv_head_num, head_size, max_seq_len, step,
-                                    step_dev, workspace, workspace_bytes, rope, rot_dim, st);
+                                    step_dev, workspace, workspace_bytes, rope, rot_dim, tickets, st);
 }
 
 }  // namespace llmie
@@ -451,10 +509,34 @@ extern "C" int llmie_decoder_mha(const void *qkv, const void *qkv_bias, void *k_
     if (dtype == LLMIE_F32)
         return decoder_mha_impl<float>((const float *)qkv, (const float *)qkv_bias, (float *)k_cache, (float *)v_cache,
                                        (float *)out, layer, batch, head_num, kv_head_num, head_size, max_seq_len, step,
-                                       step_dev, workspace, workspace_bytes, nullptr, 0, as_stream(stream));
+                                       step_dev, workspace, workspace_bytes, nullptr, 0, nullptr, as_stream(stream));
     if (dtype == LLMIE_F16)
         return decoder_mha_impl<half_t>((const half_t *)qkv, (const half_t *)qkv_bias, (half_t *)k_cache,
                                         (half_t *)v_cache, (half_t *)out, layer, batch, head_num, kv_head_num, head_size,
-                                        max_seq_len, step, step_dev, workspace, workspace_bytes, nullptr, 0, as_stream(stream));
+                                        max_seq_len, step, step_dev, workspace, workspace_bytes, nullptr, 0, nullptr, as_stream(stream));
     LLMIE_UNSUPPORTED("decoder_mha: dtype %d", (int)dtype);
+}
+
+extern "C" int llmie_decoder_mha_rope(const void *qkv, const void *qkv_bias, void *k_cache, void *v_cache, void *out,
+                                      int layer, int batch, int head_num, int kv_head_num, int head_size,
+                                      int max_seq_len, int step, const int32_t *step_dev, void *workspace,
+                                      size_t workspace_bytes, const void *rope_table, int rotary_dim, int32_t *tickets,
+                                      llmie_dtype dtype, llmie_stream stream) {
+    LLMIE_REQUIRE(qkv && k_cache && v_cache && out, "decoder_mha_rope: NULL pointer");
+    LLMIE_REQUIRE(layer >= 0 && batch > 0 && head_num > 0 && kv_head_num > 0 && head_size > 0 && max_seq_len > 0,
+                  "decoder_mha_rope: bad shape");
+    LLMIE_REQUIRE(head_num % kv_head_num == 0, "decoder_mha_rope: kv_head_num must divide head_num");
+    LLMIE_REQUIRE(step_dev || (step >= 1 && step <= max_seq_len), "decoder_mha_rope: step %d outside [1, max_seq_len=%d]",
+                  step, max_seq_len);
+    LLMIE_REQUIRE(!rope_table || (rotary_dim > 0 && rotary_dim % 2 == 0), "decoder_mha_rope: bad rotary_dim");
+    if (dtype != LLMIE_F32 && dtype != LLMIE_F16) LLMIE_UNSUPPORTED("decoder_mha_rope: dtype %d", (int)dtype);
+    const int rep = head_num / kv_head_num;
+    const bool hs_ok = head_size == 32 || head_size == 64 || head_size == 128 || head_size == 256;
+    const bool rep_ok = rep == 1 || rep == 2 || rep == 4 || rep == 8;
+    if ((rope_table || tickets) && !(hs_ok && rep_ok))
+        LLMIE_UNSUPPORTED("decoder_mha_rope: fused RoPE / in-launch merge need head_size in {32,64,128,256} and "
+                          "head_num/kv_head_num in {1,2,4,8}");
+    return decoder_mha_rope(qkv, qkv_bias, k_cache, v_cache, out, layer, batch, head_num, kv_head_num, head_size,
+                            max_seq_len, step, step_dev, workspace, workspace_bytes,
+                            static_cast<const float2 *>(rope_table), rotary_dim, tickets, dtype, as_stream(stream));
 }

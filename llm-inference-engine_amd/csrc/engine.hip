@@ -29,6 +29,7 @@ struct llmie_decoder {
     void *attn_ws;
     size_t attn_ws_bytes;
     float2 *rope_table;  // [max_seq_len][head_size/2] (cos, sin), host-computed at create
+    int32_t *tickets;    // [max_batch, kv_head_num] arrival counters of the in-launch attention merge (zero between launches)
     // profiling (eager only)
     bool profiling = false;
     std::vector<hipEvent_t> ev;      // pairs: start, stop
@@ -84,7 +85,7 @@ struct Carve {
     }
 };
 
-static size_t carve(const llmie_decoder_config *c, size_t *offs /*[8]*/) {
+static size_t carve(const llmie_decoder_config *c, size_t *offs /*[9]*/) {
     const size_t e = c->dtype == LLMIE_F16 ? 2 : 4;
     const size_t B = c->max_batch, H = static_cast<size_t>(c->head_num) * c->head_size;
     const size_t QKV = static_cast<size_t>(c->head_num + 2 * c->kv_head_num) * c->head_size;
@@ -98,12 +99,13 @@ static size_t carve(const llmie_decoder_config *c, size_t *offs /*[8]*/) {
     offs[5] = k.take(B * 2 * I * e);    // gate_up (unfused paths)
     offs[6] = k.take(llmie_decoder_mha_workspace_bytes(c->max_batch, c->head_num, c->head_size, c->max_seq_len));
     offs[7] = k.take(static_cast<size_t>(c->max_seq_len) * (c->head_size / 2) * sizeof(float2));  // RoPE table
+    offs[8] = k.take(static_cast<size_t>(c->max_batch) * c->kv_head_num * sizeof(int32_t));         // merge tickets
     return k.off;
 }
 
 extern "C" size_t llmie_decoder_workspace_bytes(const llmie_decoder_config *cfg) {
     if (!config_ok(cfg)) return 0;
-    size_t offs[8];
+    size_t offs[9];
     return carve(cfg, offs);
 }
 
@@ -117,7 +119,7 @@ extern "C" llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg, 
         set_error("decoder_create: NULL layers/workspace");
         return nullptr;
     }
-    size_t offs[8];
+    size_t offs[9];
     const size_t need = carve(cfg, offs);
     if (workspace_bytes < need) {
         set_error("decoder_create: workspace too small (%zu < %zu)", workspace_bytes, need);
@@ -157,6 +159,12 @@ extern "C" llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg, 
     d->attn_ws = base + offs[6];
     d->attn_ws_bytes = llmie_decoder_mha_workspace_bytes(cfg->max_batch, cfg->head_num, cfg->head_size, cfg->max_seq_len);
     d->rope_table = reinterpret_cast<float2 *>(base + offs[7]);
+    d->tickets = reinterpret_cast<int32_t *>(base + offs[8]);
+    if (hipMemset(d->tickets, 0, static_cast<size_t>(cfg->max_batch) * cfg->kv_head_num * sizeof(int32_t)) != hipSuccess) {
+        set_error("decoder_create: ticket memset failed");
+        delete d;
+        return nullptr;
+    }
     {
         // cos/sin of angle = pos / base^(2j/rot_dim) (rope_utils.cuh:6-19), evaluated on the host in fp32 with libm --
         // one synchronous upload at create time (the only host<->device copy the engine ever does)
@@ -298,6 +306,10 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
     if (!fused_off && c.dtype == LLMIE_F16 && c.wfmt == LLMIE_W_F16 && hs_ok && rep_ok && H % 8 == 0 &&
         gemv_f16_eligible(batch, H, h, dec->layers[0].qkv.data)) {
         hipStream_t st = as_stream(stream);
+        // In-launch merge of the attention partials (ticket + agent-scope release/acquire) measured SLOWER than the
+        // separate 4.8 us merge kernel on MI355X (2.97 vs 2.81 ms per token: every workgroup pays the release fence),
+        // so the merge kernel is the default; LLMIE_ATTN_MERGE_IN_KERNEL=1 selects the single-launch form.
+        static const bool merge_in_kernel = getenv("LLMIE_ATTN_MERGE_IN_KERNEL") != nullptr;
         for (int l = 0; l < c.num_layers; ++l) {
             const llmie_layer_weights &w = dec->layers[l];
             TIMED(LLMIE_OP_QKV_GEMM, linear_f16_nk_norm((const half_t *)h, (const half_t *)w.qkv.data, (half_t *)dec->qkv, batch, H,
@@ -305,7 +317,8 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
                                                         nullptr, c.rms_eps, st));
             TIMED(LLMIE_OP_MHA, decoder_mha_rope(dec->qkv, w.qkv.bias, k_cache, v_cache, dec->mha, l, batch, c.head_num,
                                                  c.kv_head_num, c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws,
-                                                 dec->attn_ws_bytes, dec->rope_table, c.rotary_dim, dt, st));
+                                                 dec->attn_ws_bytes, dec->rope_table, c.rotary_dim,
+                                                 merge_in_kernel ? dec->tickets : nullptr, dt, st));
             TIMED(LLMIE_OP_O_GEMM, linear_f16_nk((const half_t *)dec->mha, (const half_t *)w.o.data, (half_t *)h, batch, H, H,
                                                  EPI_NONE_, nullptr, (const half_t *)h, st));
             TIMED(LLMIE_OP_GATE_UP_SWIGLU, linear_f16_nk_norm((const half_t *)h, (const half_t *)w.gate_up.data, (half_t *)dec->act,

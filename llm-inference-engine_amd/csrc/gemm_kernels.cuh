@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
         return row < lim ? row : lim - 1;  // clamp: result of a clamped row is never stored
     };
 
-    // ---- activation slice of this thread (+ fused RMSNorm) ----
+    // ---- activation slice of this thread (issued first: L2), then the first weight group (HBM) ----
     half8_t xr[M][XC];
     const half8_t *xg = reinterpret_cast<const half8_t *>(a.x);
 #pragma unroll
@@ -80,20 +80,43 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
             const int cc = j * 256 + tid;
             xr[m][j] = cc < nch ? xg[m * nch + cc] : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
         }
+    half8_t g[XC];
     if (a.norm) {
-        const half8_t *pb = reinterpret_cast<const half8_t *>(a.pre_bias);
         const half8_t *gm = reinterpret_cast<const half8_t *>(a.gamma);
-        half8_t g[XC];
 #pragma unroll
         for (int j = 0; j < XC; ++j) {
             const int cc = j * 256 + tid;
             g[j] = cc < nch ? gm[cc] : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-            if (pb && cc < nch) {
-                const half8_t b = pb[cc];
+        }
+    }
+    half8_t wb[RPW][XC];
+    auto load_group = [&](int grp) {
 #pragma unroll
-                for (int m = 0; m < M; ++m)
+        for (int r = 0; r < RPW; ++r) {
+            const half8_t *w = reinterpret_cast<const half8_t *>(a.W + static_cast<size_t>(row_of(grp, r)) * K);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) xr[m][j][e] = from_f32<half_t>(to_f32(xr[m][j][e]) + to_f32(b[e]));
+            for (int j = 0; j < XC; ++j) {
+                const int cc = j * 256 + tid;
+                wb[r][j] = cc < nch ? load_nt(w + cc) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+    };
+    int grp = blockIdx.x;
+    if (grp < ngroups) load_group(grp);  // in flight while the norm below waits only for x / gamma
+
+    if (a.norm) {
+        const half8_t *pb = reinterpret_cast<const half8_t *>(a.pre_bias);
+        if (pb) {
+#pragma unroll
+            for (int j = 0; j < XC; ++j) {
+                const int cc = j * 256 + tid;
+                if (cc < nch) {
+                    const half8_t b = pb[cc];
+#pragma unroll
+                    for (int m = 0; m < M; ++m)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) xr[m][j][e] = from_f32<half_t>(to_f32(xr[m][j][e]) + to_f32(b[e]));
+                }
             }
         }
 #pragma unroll
@@ -115,28 +138,25 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
         }
     }
 
-    int it = 0;
-    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x, ++it) {
-        half8_t wb[RPW][XC];
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            const half8_t *w = reinterpret_cast<const half8_t *>(a.W + static_cast<size_t>(row_of(grp, r)) * K);
-#pragma unroll
-            for (int j = 0; j < XC; ++j) {
-                const int cc = j * 256 + tid;
-                wb[r][j] = cc < nch ? load_nt(w + cc) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-            }
-        }
+    for (int it = 0; grp < ngroups; ++it) {
         float acc[M][RPW];
 #pragma unroll
         for (int r = 0; r < RPW; ++r)
 #pragma unroll
             for (int m = 0; m < M; ++m) {
-                float s = 0.f;
+                float sdot = 0.f;
 #pragma unroll
-                for (int j = 0; j < XC; ++j) s = dot8(wb[r][j], xr[m][j], s);
-                acc[m][r] = wave_sum(s);
+                for (int j = 0; j < XC; ++j) sdot = dot8(wb[r][j], xr[m][j], sdot);
+                acc[m][r] = sdot;
             }
+        // the weight registers are dead now: put the next group's loads in flight before the reduction/barrier
+        const int cur = grp;
+        grp += gridDim.x;
+        if (grp < ngroups) load_group(grp);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int m = 0; m < M; ++m) acc[m][r] = wave_sum(acc[m][r]);
         float *slot = &red[it & 1][0][0];
         if (lane == 0) {
 #pragma unroll
@@ -148,7 +168,7 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
         if (swiglu) {
             if (tid < M * (RPW / 2)) {
                 const int m = tid / (RPW / 2), q = tid % (RPW / 2);
-                const int col = grp * (RPW / 2) + q;
+                const int col = cur * (RPW / 2) + q;
                 if (col < half_n) {
                     float gt = 0.f, up = 0.f;
 #pragma unroll
@@ -162,7 +182,7 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
         } else {
             if (tid < M * RPW) {
                 const int m = tid / RPW, r = tid % RPW;
-                const int col = grp * RPW + r;
+                const int col = cur * RPW + r;
                 if (col < N) {
                     float v = 0.f;
 #pragma unroll

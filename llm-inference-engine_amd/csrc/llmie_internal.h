@@ -16,10 +16,11 @@ bool gemv_f16_eligible(int M, int K, const void *x, const void *W);
 int linear_f16_nk_norm(const half_t *x, const half_t *W, half_t *y, int M, int K, int N, int epi, const half_t *bias,
                        const half_t *residual, const half_t *gamma, const half_t *pre_bias, float eps, hipStream_t st);
 
-// decode attention with RoPE fused in front (rope = [max_pos][head_size/2] (cos,sin) table); attention_decode.hip
+// decode attention with optional RoPE (rope may be null) fused in front (rope = [max_pos][head_size/2] (cos,sin) table); attention_decode.hip
 int decoder_mha_rope(const void *qkv, const void *qkv_bias, void *k_cache, void *v_cache, void *out, int layer, int batch,
                      int head_num, int kv_head_num, int head_size, int max_seq_len, int step, const int32_t *step_dev,
-                     void *workspace, size_t workspace_bytes, const float2 *rope, int rot_dim, llmie_dtype dtype,
-                     hipStream_t st);
+                     void *workspace, size_t workspace_bytes, const float2 *rope, int rot_dim,
+                     int32_t *tickets /* [batch,kvh] zeroed arrival counters: in-launch merge; null = merge kernel */,
+                     llmie_dtype dtype, hipStream_t st);
 
 }  // namespace llmie

@@ -489,3 +489,69 @@ def test_sampling_distribution(llmie):
     p = np.exp(tv[0] - tv[0].max())
     p /= p.sum()
     assert np.abs(freq - p).max() < 0.015
+
+
+# --------------------------------------------------------------------------- fused RoPE + attention + in-launch merge
+def _rope_table(max_pos, hs, rot, base=10000.0):
+    j = np.arange(hs // 2, dtype=np.float32)
+    inv = np.power(np.float32(base), (2 * j) / np.float32(rot)).astype(np.float32)
+    ang = (np.arange(max_pos, dtype=np.float32)[:, None] / inv[None, :]).astype(np.float32)
+    tab = np.stack([np.cos(ang), np.sin(ang)], axis=-1).astype(np.float32)
+    tab[:, rot // 2:, 0], tab[:, rot // 2:, 1] = 1.0, 0.0
+    return tab
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("bs,nh,kvh,hs,max_seq,step,bias,rot", [
+    (1, 32, 32, 128, 256, 129, False, 128), (2, 32, 32, 128, 2048, 2048, False, 128),
+    (3, 8, 2, 128, 300, 257, True, 128), (2, 4, 4, 32, 64, 33, False, 32), (1, 8, 8, 64, 128, 100, True, 32)])
+def test_decoder_mha_rope_fused_matches_oracle_sequence(llmie, dtype, bs, nh, kvh, hs, max_seq, step, bias, rot):
+    """rope kernel + mha kernel (oracle: orc_rope_decode then orc_decoder_mha) == the fused launch"""
+    rng = np.random.default_rng(21)
+    qkv = rnd(rng, (bs, nh + 2 * kvh, hs), 1.0, dtype)
+    b = rnd(rng, ((nh + 2 * kvh) * hs,), 0.3, dtype) if bias else None
+    kc = rnd(rng, (1, bs, kvh, max_seq, hs), 0.5, dtype)
+    vc = rnd(rng, (1, bs, kvh, max_seq, hs), 0.5, dtype)
+    kd, vd = dev(kc, dtype), dev(vc, dtype)
+    out = torch.empty((bs, nh * hs), dtype=dtype, device=DEV)
+    ws = torch.empty(llmie.decoder_mha_workspace_bytes(bs, nh, hs, max_seq) // 4, device=DEV)
+    tickets = torch.zeros(bs * kvh, dtype=torch.int32, device=DEV)
+    tab = dev(_rope_table(max_seq, hs, rot))
+    llmie.decoder_mha_rope(dev(qkv, dtype), None if b is None else dev(b, dtype), kd, vd, out, 0, nh, kvh, step, ws, tab,
+                           rot, tickets)
+    assert int(tickets.abs().sum()) == 0  # re-armed by the last arriver
+    q_rot = orc.rope_decode(qkv, nh, kvh, hs, step, rot, 10000.0)
+    if dtype == torch.float16:
+        q_rot = q_rot.astype(np.float16).astype(np.float32)  # the unfused path stores the rotated q/k in fp16
+    eo = orc.decoder_mha(q_rot, b, kc, vc, 0, nh, kvh, hs, step)
+    close(host(out), eo, *tol(dtype, f32=(2e-4, 2e-5), f16=(3e-3, 2e-3)))
+    # appended k row = rotated k: the numpy table above and the oracle's libm angle differ by ~1 ulp(angle) ~ step*6e-8
+    close(host(kd), kc.astype(np.float16).astype(np.float32) if dtype == torch.float16 else kc, 0,
+          2e-3 if dtype == torch.float16 else 3e-4 * max(1.0, step / 256))
+
+
+def test_in_launch_merge_is_bit_identical_to_merge_kernel_under_load(llmie):
+    """Hand-off hazard test (Guideline 16): many back-to-back launches re-using the same partial slabs and ticket
+    words with fresh data each time, both XCD-spread (bs*kvh*splits workgroups) and L1/L2-warm; every output word of
+    the in-launch merge must equal the separate merge kernel's, and the tickets must always return to zero."""
+    rng = np.random.default_rng(22)
+    bs, nh, hs, max_seq = 4, 32, 128, 2048
+    ws1 = torch.empty(llmie.decoder_mha_workspace_bytes(bs, nh, hs, max_seq) // 4, device=DEV)
+    ws2 = torch.empty_like(ws1)
+    tickets = torch.zeros(bs * nh, dtype=torch.int32, device=DEV)
+    tab = dev(_rope_table(max_seq, hs, hs))
+    kc = dev(rnd(rng, (1, bs, nh, max_seq, hs), 0.5, torch.float16), torch.float16)
+    vc = dev(rnd(rng, (1, bs, nh, max_seq, hs), 0.5, torch.float16), torch.float16)
+    o1 = torch.empty((bs, nh * hs), dtype=torch.float16, device=DEV)
+    o2 = torch.empty_like(o1)
+    big = torch.empty(64 << 20, dtype=torch.float32, device=DEV)
+    for it in range(60):
+        step = int(rng.integers(130, max_seq + 1))
+        qkv = torch.randn((bs, 3 * nh, hs), device=DEV).to(torch.float16)
+        k1, v1, k2, v2 = kc.clone(), vc.clone(), kc.clone(), vc.clone()
+        if it % 3 == 0:
+            big.add_(1.0)  # concurrent-ish streaming traffic right before the launch (uneven load, evictions)
+        llmie.decoder_mha_rope(qkv, None, k1, v1, o1, 0, nh, nh, step, ws1, tab, hs, tickets)
+        llmie.decoder_mha_rope(qkv, None, k2, v2, o2, 0, nh, nh, step, ws2, tab, hs, None)
+        assert torch.equal(o1, o2), "iteration %d (step %d): in-launch merge differs" % (it, step)
+        assert int(tickets.abs().sum()) == 0
