@@ -365,3 +365,24 @@ class Decoder:
             self.close()
         except Exception:
             pass
+
+
+# ------------------------------------------------------------------ weight-only quantised linears
+def quantize_w8(w, wq, scale):
+    _check(lib().llmie_quantize_w8(_p(w), _p(wq), _p(scale), w.shape[0], w.shape[1], _st()), "quantize_w8")
+
+
+def quantize_w4(w, wq, scale, group):
+    _check(lib().llmie_quantize_w4(_p(w), _p(wq), _p(scale), w.shape[0], w.shape[1], group, _st()), "quantize_w4")
+
+
+def linear_w8a16(x, wq, scale, y, bias=None, residual=None):
+    _check(lib().llmie_linear_w8a16(_p(x), _p(wq), _p(scale), _p(y), x.shape[0], x.shape[1], wq.shape[0], _p(bias),
+                                    _p(residual), _st()), "linear_w8a16")
+    return y
+
+
+def linear_w4a16(x, wq, scale, y, group, bias=None, residual=None):
+    _check(lib().llmie_linear_w4a16(_p(x), _p(wq), _p(scale), _p(y), x.shape[0], x.shape[1], wq.shape[0], group,
+                                    _p(bias), _p(residual), _st()), "linear_w4a16")
+    return y

@@ -303,30 +303,40 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
     const int rep = c.head_num / c.kv_head_num;
     const bool hs_ok = c.head_size == 32 || c.head_size == 64 || c.head_size == 128 || c.head_size == 256;
     const bool rep_ok = rep == 1 || rep == 2 || rep == 4 || rep == 8;
-    if (!fused_off && c.dtype == LLMIE_F16 && c.wfmt == LLMIE_W_F16 && hs_ok && rep_ok && H % 8 == 0 &&
-        gemv_f16_eligible(batch, H, h, dec->layers[0].qkv.data)) {
+    const int wbits = c.wfmt == LLMIE_W_F16 ? 16 : (c.wfmt == LLMIE_W_INT8 ? 8 : (c.wfmt == LLMIE_W_INT4 ? 4 : 0));
+    const bool gemv_ok = wbits == 16 ? gemv_f16_eligible(batch, H, h, dec->layers[0].qkv.data)
+                                     : (wbits != 0 && ksplit_eligible(batch, H, wbits));
+    if (!fused_off && c.dtype == LLMIE_F16 && wbits != 0 && hs_ok && rep_ok && H % 8 == 0 && gemv_ok) {
         hipStream_t st = as_stream(stream);
         // In-launch merge of the attention partials (ticket + agent-scope release/acquire) measured SLOWER than the
         // separate 4.8 us merge kernel on MI355X (2.97 vs 2.81 ms per token: every workgroup pays the release fence),
         // so the merge kernel is the default; LLMIE_ATTN_MERGE_IN_KERNEL=1 selects the single-launch form.
         static const bool merge_in_kernel = getenv("LLMIE_ATTN_MERGE_IN_KERNEL") != nullptr;
+        // y = [swiglu]( rmsnorm(x + pre_bias)*gamma . W^T ) + residual on the streaming GEMV of the weight format
+        auto lin = [&](const void *x, const llmie_matrix &w, void *y, int K, int N, int epi, const void *residual,
+                       const void *gamma, const void *pre_bias) -> int {
+            if (wbits == 16) {
+                if (gamma)
+                    return linear_f16_nk_norm((const half_t *)x, (const half_t *)w.data, (half_t *)y, batch, K, N, epi, nullptr,
+                                              (const half_t *)residual, (const half_t *)gamma, (const half_t *)pre_bias,
+                                              c.rms_eps, st);
+                return linear_f16_nk((const half_t *)x, (const half_t *)w.data, (half_t *)y, batch, K, N, epi, nullptr,
+                                     (const half_t *)residual, st);
+            }
+            return linear_wq(wbits, (const half_t *)x, w.data, (const half_t *)w.scale, (half_t *)y, batch, K, N, c.int4_group,
+                             epi, nullptr, (const half_t *)residual, (const half_t *)gamma, (const half_t *)pre_bias,
+                             c.rms_eps, st);
+        };
         for (int l = 0; l < c.num_layers; ++l) {
             const llmie_layer_weights &w = dec->layers[l];
-            TIMED(LLMIE_OP_QKV_GEMM, linear_f16_nk_norm((const half_t *)h, (const half_t *)w.qkv.data, (half_t *)dec->qkv, batch, H,
-                                                        QKV, EPI_NONE_, nullptr, nullptr, (const half_t *)w.attn_norm_gamma,
-                                                        nullptr, c.rms_eps, st));
+            TIMED(LLMIE_OP_QKV_GEMM, lin(h, w.qkv, dec->qkv, H, QKV, EPI_NONE_, nullptr, w.attn_norm_gamma, nullptr));
             TIMED(LLMIE_OP_MHA, decoder_mha_rope(dec->qkv, w.qkv.bias, k_cache, v_cache, dec->mha, l, batch, c.head_num,
                                                  c.kv_head_num, c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws,
                                                  dec->attn_ws_bytes, dec->rope_table, c.rotary_dim,
                                                  merge_in_kernel ? dec->tickets : nullptr, dt, st));
-            TIMED(LLMIE_OP_O_GEMM, linear_f16_nk((const half_t *)dec->mha, (const half_t *)w.o.data, (half_t *)h, batch, H, H,
-                                                 EPI_NONE_, nullptr, (const half_t *)h, st));
-            TIMED(LLMIE_OP_GATE_UP_SWIGLU, linear_f16_nk_norm((const half_t *)h, (const half_t *)w.gate_up.data, (half_t *)dec->act,
-                                                              batch, H, 2 * I, EPI_SWIGLU_, nullptr, nullptr,
-                                                              (const half_t *)w.ffn_norm_gamma, (const half_t *)w.o.bias,
-                                                              c.rms_eps, st));
-            TIMED(LLMIE_OP_DOWN_GEMM, linear_f16_nk((const half_t *)dec->act, (const half_t *)w.down.data, (half_t *)h, batch, I, H,
-                                                    EPI_NONE_, nullptr, (const half_t *)h, st));
+            TIMED(LLMIE_OP_O_GEMM, lin(dec->mha, w.o, h, H, H, EPI_NONE_, h, nullptr, nullptr));
+            TIMED(LLMIE_OP_GATE_UP_SWIGLU, lin(h, w.gate_up, dec->act, H, 2 * I, EPI_SWIGLU_, nullptr, w.ffn_norm_gamma, w.o.bias));
+            TIMED(LLMIE_OP_DOWN_GEMM, lin(dec->act, w.down, h, I, H, EPI_NONE_, h, nullptr, nullptr));
         }
         return LLMIE_OK;
     }

@@ -33,7 +33,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------
 struct GemvArgs {
     const half_t *x;         // [M,K]
-    const half_t *W;         // [N,K]
+    const void *W;           // [N,K] fp16 | int8 | packed int4 (K/2 bytes per row)
     half_t *y;
     int K, N;
     const half_t *bias;      // [N] or null (EPI_NONE)
@@ -42,22 +42,84 @@ struct GemvArgs {
     const half_t *pre_bias;  // [K] or null (norm)
     float eps;
     int epi, norm;
+    const void *scale;       // int8: fp16 [N]; int4: fp16 [N, K/group]; fp16 weights: null
+    int group;               // int4 group size (multiple of 32)
 };
+
+// ---- weight formats of the K-split GEMV: a 16-byte chunk holds 8 fp16, 16 int8 or 32 int4 weights ----
+// int8 / int4 are de-quantised in registers with the fp16 "magic number" trick (0x6400 | u = 1024 + u exactly),
+// two weights per v_perm/v_and + one packed subtract, and fed to v_dot2_f32_f16 like the fp16 stream; the
+// per-row (int8) or per-(row, group) (int4) scale is applied to the fp32 partial sum.
+typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+
+template <int WBITS> struct WFmt;
+template <> struct WFmt<16> { static constexpr int XE = 1; };  // half8 of x per chunk
+template <> struct WFmt<8> { static constexpr int XE = 2; };
+template <> struct WFmt<4> { static constexpr int XE = 4; };
+
+__device__ __forceinline__ half2_t as_half2(unsigned int u) { return __builtin_bit_cast(half2_t, u); }
+
+// dot of one 16-byte weight chunk with its activation chunk(s); x is in natural k order for 16/8 bit and in the
+// permuted order produced by permute_x_int4() for 4 bit.
+template <int WBITS>
+__device__ __forceinline__ float chunk_dot(const uint4_t w, const half8_t (&x)[WFmt<WBITS>::XE], float acc) {
+    if constexpr (WBITS == 16) {
+        return dot8(__builtin_bit_cast(half8_t, w), x[0], acc);
+    } else if constexpr (WBITS == 8) {
+        // bytes b0..b3 of a word -> halves (b0,b1), (b2,b3) as 1024 + (b ^ 0x80) = 1152 + int8
+        const half2_t off = {static_cast<half_t>(1152.f), static_cast<half_t>(1152.f)};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned int v = w[i] ^ 0x80808080u;
+            const unsigned int lo = __builtin_amdgcn_perm(0x64646464u, v, 0x04010400u);  // {0x64,b1,0x64,b0}
+            const unsigned int hi = __builtin_amdgcn_perm(0x64646464u, v, 0x04030402u);  // {0x64,b3,0x64,b2}
+            const half2_t wlo = as_half2(lo) - off, whi = as_half2(hi) - off;
+            const half8_t xv = x[i >> 1];
+            const int b = (i & 1) * 4;
+            acc = __builtin_amdgcn_fdot2(wlo, half2_t{xv[b], xv[b + 1]}, acc, false);
+            acc = __builtin_amdgcn_fdot2(whi, half2_t{xv[b + 2], xv[b + 3]}, acc, false);
+        }
+        return acc;
+    } else {
+        // word i holds k = 8i..8i+7 as nibbles n0..n7; (w >> 4s) & 0x000F000F = (n_s, n_{s+4}) -> 1024 + n; value = n - 8
+        const half2_t off = {static_cast<half_t>(1032.f), static_cast<half_t>(1032.f)};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const half8_t xv = x[i];  // permuted: (k0,k4,k1,k5,k2,k6,k3,k7) of this word
+#pragma unroll
+            for (int sft = 0; sft < 4; ++sft) {
+                const unsigned int u = ((w[i] >> (4 * sft)) & 0x000F000Fu) | 0x64006400u;
+                acc = __builtin_amdgcn_fdot2(as_half2(u) - off, half2_t{xv[2 * sft], xv[2 * sft + 1]}, acc, false);
+            }
+        }
+        return acc;
+    }
+}
+// activation order matching chunk_dot<4>: within each group of 8: (0,4,1,5,2,6,3,7)
+__device__ __forceinline__ half8_t permute_x_int4(const half8_t v) {
+    return half8_t{v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7]};
+}
 
 // K-split GEMV (the hot kernel).  One workgroup = 256 threads owns RPW rows per iteration and splits
 // K: thread t streams the 16-byte chunks t, t+256, ... of every row (a workgroup instruction covers
 // 4 KiB contiguous of one row), so the activation slice a thread needs is XC chunks and lives in
 // registers -- no LDS staging, no barrier in front of the stream; RPW*XC loads are in flight per lane.
-// The 4 waves meet once per iteration to add their partial sums through a double-buffered LDS slot.
-// Measured (tools/gemv_bench.hip, MI355X, incl. ~1 us launch gap): QKV 100.7 MB 16.7 us, O 33.6 MB
+// The first group's loads are issued before the (fused) RMSNorm prologue and the next group's loads
+// right after the dot products, before the cross-wave reduction.  The 4 waves meet once per iteration to
+// add their partial sums through a double-buffered LDS slot.
+// Measured fp16 (tools/gemv_bench.hip, MI355X, incl. ~1 us launch gap): QKV 100.7 MB 16.7 us, O 33.6 MB
 // 7.6 us, down 90.2 MB 16.1 us, LM head 262 MB 42 us = 6.0 / 4.4 / 5.6 / 6.2 TB/s.
-template <int M, int RPW, int XC>
+template <int M, int RPW, int XC, int WBITS>
 __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
     static_assert(RPW % 2 == 0, "rows come in pairs");
+    constexpr int XE = WFmt<WBITS>::XE;   // half8 activations per weight chunk
+    constexpr int EPC = 8 * XE;           // weights per 16-byte chunk
     __shared__ float red[2][4][M * RPW];
     __shared__ float ssq[4][M];
     const int K = a.K, N = a.N;
-    const int nch = K >> 3;
+    const int nch = K / EPC;              // chunks per row
+    const int nx8 = K >> 3;               // half8 per activation row
+    const size_t row_bytes = static_cast<size_t>(K) * WBITS / 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool swiglu = a.epi == EPI_SWIGLU;
     const int half_n = N >> 1;
@@ -71,33 +133,37 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
     };
 
     // ---- activation slice of this thread (issued first: L2), then the first weight group (HBM) ----
-    half8_t xr[M][XC];
+    half8_t xr[M][XC][XE];
     const half8_t *xg = reinterpret_cast<const half8_t *>(a.x);
 #pragma unroll
     for (int m = 0; m < M; ++m)
 #pragma unroll
         for (int j = 0; j < XC; ++j) {
             const int cc = j * 256 + tid;
-            xr[m][j] = cc < nch ? xg[m * nch + cc] : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < XE; ++e)
+                xr[m][j][e] = cc < nch ? xg[m * nx8 + cc * XE + e] : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
         }
-    half8_t g[XC];
+    half8_t g[XC][XE];
     if (a.norm) {
         const half8_t *gm = reinterpret_cast<const half8_t *>(a.gamma);
 #pragma unroll
         for (int j = 0; j < XC; ++j) {
             const int cc = j * 256 + tid;
-            g[j] = cc < nch ? gm[cc] : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < XE; ++e) g[j][e] = cc < nch ? gm[cc * XE + e] : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
-    half8_t wb[RPW][XC];
+    uint4_t wb[RPW][XC];
+    const unsigned char *Wb = reinterpret_cast<const unsigned char *>(a.W);
     auto load_group = [&](int grp) {
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
-            const half8_t *w = reinterpret_cast<const half8_t *>(a.W + static_cast<size_t>(row_of(grp, r)) * K);
+            const uint4_t *w = reinterpret_cast<const uint4_t *>(Wb + static_cast<size_t>(row_of(grp, r)) * row_bytes);
 #pragma unroll
             for (int j = 0; j < XC; ++j) {
                 const int cc = j * 256 + tid;
-                wb[r][j] = cc < nch ? load_nt(w + cc) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                wb[r][j] = cc < nch ? load_nt(w + cc) : uint4_t{0, 0, 0, 0};
             }
         }
     };
@@ -111,11 +177,14 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
             for (int j = 0; j < XC; ++j) {
                 const int cc = j * 256 + tid;
                 if (cc < nch) {
-                    const half8_t b = pb[cc];
 #pragma unroll
-                    for (int m = 0; m < M; ++m)
+                    for (int e = 0; e < XE; ++e) {
+                        const half8_t b = pb[cc * XE + e];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) xr[m][j][e] = from_f32<half_t>(to_f32(xr[m][j][e]) + to_f32(b[e]));
+                        for (int m = 0; m < M; ++m)
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) xr[m][j][e][i] = from_f32<half_t>(to_f32(xr[m][j][e][i]) + to_f32(b[i]));
+                    }
                 }
             }
         }
@@ -123,7 +192,9 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
         for (int m = 0; m < M; ++m) {
             float ss = 0.f;
 #pragma unroll
-            for (int j = 0; j < XC; ++j) ss = dot8(xr[m][j], xr[m][j], ss);
+            for (int j = 0; j < XC; ++j)
+#pragma unroll
+                for (int e = 0; e < XE; ++e) ss = dot8(xr[m][j][e], xr[m][j][e], ss);
             ss = wave_sum(ss);
             if (lane == 0) ssq[wave][m] = ss;
         }
@@ -134,21 +205,48 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
 #pragma unroll
             for (int j = 0; j < XC; ++j)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) xr[m][j][e] = from_f32<half_t>(to_f32(xr[m][j][e]) * to_f32(g[j][e]) * inv);
+                for (int e = 0; e < XE; ++e)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        xr[m][j][e][i] = from_f32<half_t>(to_f32(xr[m][j][e][i]) * to_f32(g[j][e][i]) * inv);
         }
     }
+    if constexpr (WBITS == 4) {
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+#pragma unroll
+            for (int j = 0; j < XC; ++j)
+#pragma unroll
+                for (int e = 0; e < XE; ++e) xr[m][j][e] = permute_x_int4(xr[m][j][e]);
+    }
+    const half_t *scale = reinterpret_cast<const half_t *>(a.scale);
+    const int sgroups = (WBITS == 4) ? K / a.group : 1;  // scales per row
 
     for (int it = 0; grp < ngroups; ++it) {
         float acc[M][RPW];
 #pragma unroll
-        for (int r = 0; r < RPW; ++r)
+        for (int r = 0; r < RPW; ++r) {
+            float sc[XC];
+            if constexpr (WBITS == 4) {
+                // one scale per (row, k-group); a 32-weight chunk lies inside one group (group % 32 == 0)
+                const half_t *srow = scale + static_cast<size_t>(row_of(grp, r)) * sgroups;
+#pragma unroll
+                for (int j = 0; j < XC; ++j) {
+                    const int cc = j * 256 + tid;
+                    sc[j] = cc < nch ? to_f32(srow[(cc * EPC) / a.group]) : 0.f;
+                }
+            }
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 float sdot = 0.f;
 #pragma unroll
-                for (int j = 0; j < XC; ++j) sdot = dot8(wb[r][j], xr[m][j], sdot);
+                for (int j = 0; j < XC; ++j) {
+                    if constexpr (WBITS == 4) sdot = fmaf(sc[j], chunk_dot<4>(wb[r][j], xr[m][j], 0.f), sdot);
+                    else sdot = chunk_dot<WBITS>(wb[r][j], xr[m][j], sdot);
+                }
                 acc[m][r] = sdot;
             }
+        }
         // the weight registers are dead now: put the next group's loads in flight before the reduction/barrier
         const int cur = grp;
         grp += gridDim.x;
@@ -165,6 +263,7 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
                 for (int r = 0; r < RPW; ++r) slot[wave * (M * RPW) + m * RPW + r] = acc[m][r];
         }
         __syncthreads();  // one barrier per iteration: the other parity slot is free for the next iteration
+        auto row_scale = [&](int row) { return (WBITS == 8) ? to_f32(scale[row]) : 1.0f; };
         if (swiglu) {
             if (tid < M * (RPW / 2)) {
                 const int m = tid / (RPW / 2), q = tid % (RPW / 2);
@@ -176,6 +275,8 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
                         gt += slot[w * (M * RPW) + m * RPW + 2 * q];
                         up += slot[w * (M * RPW) + m * RPW + 2 * q + 1];
                     }
+                    gt *= row_scale(col);
+                    up *= row_scale(col + half_n);
                     a.y[static_cast<size_t>(m) * out_n + col] = from_f32<half_t>((gt / (1.0f + expf(-gt))) * up);
                 }
             }
@@ -187,6 +288,7 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
                     float v = 0.f;
 #pragma unroll
                     for (int w = 0; w < 4; ++w) v += slot[w * (M * RPW) + m * RPW + r];
+                    v *= row_scale(col);
                     if (a.bias) v += to_f32(a.bias[col]);
                     if (a.residual) v += to_f32(a.residual[static_cast<size_t>(m) * N + col]);
                     a.y[static_cast<size_t>(m) * N + col] = from_f32<half_t>(v);
@@ -250,8 +352,8 @@ __global__ __launch_bounds__(256) void gemv_lds_kernel(const GemvArgs a) {
     for (int pair = blockIdx.x * 4 + wave; pair < npairs; pair += gridDim.x * 4) {
         const int r0 = swiglu ? pair : 2 * pair;
         const int r1 = swiglu ? pair + half_n : min(2 * pair + 1, N - 1);  // odd N: duplicate row, result discarded
-        const half8_t *w0 = reinterpret_cast<const half8_t *>(a.W + static_cast<size_t>(r0) * K);
-        const half8_t *w1 = reinterpret_cast<const half8_t *>(a.W + static_cast<size_t>(r1) * K);
+        const half8_t *w0 = reinterpret_cast<const half8_t *>(static_cast<const half_t *>(a.W) + static_cast<size_t>(r0) * K);
+        const half8_t *w1 = reinterpret_cast<const half8_t *>(static_cast<const half_t *>(a.W) + static_cast<size_t>(r1) * K);
         float acc0[M], acc1[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) acc0[m] = acc1[m] = 0.f;

@@ -18,34 +18,58 @@ static int decode_gemm_mode() {
 }
 
 // ---- decode GEMV dispatch ----
-// K-split kernel: XC = chunks per thread = ceil(K/8/256) rounded up to {1,2,4,6,8}; RPW rows per iteration so
-// that RPW*XC ~ 16 loads are in flight per lane; register budget M*XC <= 16.
-template <int M, int RPW, int XC> static void launch_ksplit(const GemvArgs &a, hipStream_t st) {
+// K-split kernel: XC = 16-byte chunks per thread = ceil(K*WBITS/128/256) rounded up to {1,2,3,4,6,8}; RPW rows per
+// iteration so that RPW*XC ~ 16 loads are in flight per lane; register budget M*XC*XE <= 16 half8 of activations.
+template <int M, int RPW, int XC, int WBITS> static void launch_ksplit(const GemvArgs &a, hipStream_t st) {
     const bool swiglu = a.epi == EPI_SWIGLU;
     const int groups = swiglu ? (a.N / 2 + RPW / 2 - 1) / (RPW / 2) : (a.N + RPW - 1) / RPW;
     // long-lived workgroups (the prologue -- activation slice + norm -- is paid once per workgroup), evenly loaded
     static const int target = env_int("LLMIE_GEMV_TARGET_WGS", 768);
     const int iters = (groups + target - 1) / target;
     const int grid = (groups + iters - 1) / iters;
-    gemv_ksplit_kernel<M, RPW, XC><<<grid, 256, 0, st>>>(a);
+    gemv_ksplit_kernel<M, RPW, XC, WBITS><<<grid, 256, 0, st>>>(a);
 }
 
-template <int M> static bool dispatch_ksplit(const GemvArgs &a, hipStream_t st) {
-    const int xc = (a.K / 8 + 255) / 256;
-    if (xc <= 1) { launch_ksplit<M, 8, 1>(a, st); return true; }
-    if (xc <= 2) { launch_ksplit<M, 8, 2>(a, st); return true; }
-    if constexpr (M <= 4) {
-        if (xc <= 4) { launch_ksplit<M, 4, 4>(a, st); return true; }
+static int ksplit_xc(int K, int wbits) { return (K * wbits / 128 + 255) / 256; }
+
+template <int M, int WBITS> static bool dispatch_ksplit(const GemvArgs &a, hipStream_t st) {
+    constexpr int XE = WFmt<WBITS>::XE;
+    const int xc = ksplit_xc(a.K, WBITS);
+    if constexpr (M * 1 * XE <= 16) {
+        if (xc <= 1) { launch_ksplit<M, (WBITS == 16 ? 8 : 16), 1, WBITS>(a, st); return true; }
     }
-    if constexpr (M <= 2) {
-        if (xc <= 6) { launch_ksplit<M, 4, 6>(a, st); return true; }
-        if (xc <= 8) { launch_ksplit<M, 2, 8>(a, st); return true; }
+    if constexpr (M * 2 * XE <= 16) {
+        if (xc <= 2) { launch_ksplit<M, 8, 2, WBITS>(a, st); return true; }
+    }
+    if constexpr (M * 3 * XE <= 16 && WBITS != 16) {
+        if (xc <= 3) { launch_ksplit<M, 4, 3, WBITS>(a, st); return true; }
+    }
+    if constexpr (M * 4 * XE <= 16 && WBITS == 16) {
+        if (xc <= 4) { launch_ksplit<M, 4, 4, WBITS>(a, st); return true; }
+    }
+    if constexpr (M * 6 * XE <= 16 && WBITS == 16) {
+        if (xc <= 6) { launch_ksplit<M, 4, 6, WBITS>(a, st); return true; }
+    }
+    if constexpr (M * 8 * XE <= 16 && WBITS == 16) {
+        if (xc <= 8) { launch_ksplit<M, 2, 8, WBITS>(a, st); return true; }
     }
     return false;
 }
 
+bool ksplit_eligible(int M, int K, int wbits) {
+    const int xe = wbits == 16 ? 1 : (wbits == 8 ? 2 : 4);
+    const int xc = ksplit_xc(K, wbits);
+    if (K % (128 / wbits) != 0) return false;  // whole 16-byte chunks
+    int xcr;  // the XC the dispatcher would round to
+    if (xc <= 1) xcr = 1;
+    else if (xc <= 2) xcr = 2;
+    else if (wbits != 16) xcr = xc <= 3 ? 3 : 99;
+    else xcr = xc <= 4 ? 4 : (xc <= 6 ? 6 : (xc <= 8 ? 8 : 99));
+    return M >= 1 && M <= 8 && M * xcr * xe <= 16;
+}
+
 template <int M> static bool dispatch_gemv_m(const GemvArgs &a, hipStream_t st) {
-    if (dispatch_ksplit<M>(a, st)) return true;
+    if (dispatch_ksplit<M, 16>(a, st)) return true;
     if (static_cast<size_t>(M) * a.K * 2 > 64 * 1024) return false;
     const bool swiglu = a.epi == EPI_SWIGLU;
     const int npairs = swiglu ? a.N / 2 : (a.N + 1) / 2;
@@ -67,6 +91,24 @@ static bool dispatch_gemv(int M, const GemvArgs &a, hipStream_t st) {
         case 8: return dispatch_gemv_m<8>(a, st);
         default: return false;
     }
+}
+
+// quantised-weight GEMV (M <= 8): true when launched
+template <int WBITS> static bool dispatch_gemv_q(int M, const GemvArgs &a, hipStream_t st) {
+    switch (M) {
+        case 1: return dispatch_ksplit<1, WBITS>(a, st);
+        case 2: return dispatch_ksplit<2, WBITS>(a, st);
+        case 3: return dispatch_ksplit<3, WBITS>(a, st);
+        case 4: return dispatch_ksplit<4, WBITS>(a, st);
+        case 5: return dispatch_ksplit<5, WBITS>(a, st);
+        case 6: return dispatch_ksplit<6, WBITS>(a, st);
+        case 7: return dispatch_ksplit<7, WBITS>(a, st);
+        case 8: return dispatch_ksplit<8, WBITS>(a, st);
+        default: return false;
+    }
+}
+bool gemv_q_launch(int wbits, int M, const GemvArgs &a, hipStream_t st) {
+    return wbits == 8 ? dispatch_gemv_q<8>(M, a, st) : dispatch_gemv_q<4>(M, a, st);
 }
 
 template <int EPI>
@@ -114,9 +156,7 @@ bool gemv_f16_eligible(int M, int K, const void *x, const void *W) {
     if (K % 8 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) % 16) || M < 1 || M > 8 ||
         decode_gemm_mode() == 2)
         return false;
-    const int xc = (K / 8 + 255) / 256;
-    const bool ksplit = xc <= 2 || (M <= 4 && xc <= 4) || (M <= 2 && xc <= 8);
-    return ksplit || static_cast<size_t>(M) * K * 2 <= 64 * 1024;
+    return ksplit_eligible(M, K, 16) || static_cast<size_t>(M) * K * 2 <= 64 * 1024;
 }
 
 int linear_f16_nk_norm(const half_t *x, const half_t *W, half_t *y, int M, int K, int N, int epi, const half_t *bias,
@@ -126,7 +166,7 @@ int linear_f16_nk_norm(const half_t *x, const half_t *W, half_t *y, int M, int K
         set_error("linear(norm-fused): shape M=%d K=%d not on the GEMV path", M, K);
         return LLMIE_ERR_UNSUPPORTED;
     }
-    const GemvArgs a{x, W, y, K, N, bias, residual, gamma, pre_bias, eps, epi, 1};
+    const GemvArgs a{x, W, y, K, N, bias, residual, gamma, pre_bias, eps, epi, 1, nullptr, 0};
     dispatch_gemv(M, a, st);
     return launch_status("linear(norm-fused)");
 }
@@ -136,7 +176,7 @@ int linear_f16_nk(const half_t *x, const half_t *W, half_t *y, int M, int K, int
     const bool aligned = (K % 8 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) % 16 == 0);
     bool done = false;
     if (gemv_f16_eligible(M, K, x, W)) {
-        const GemvArgs a{x, W, y, K, N, bias, residual, nullptr, nullptr, 0.f, epi, 0};
+        const GemvArgs a{x, W, y, K, N, bias, residual, nullptr, nullptr, 0.f, epi, 0, nullptr, 0};
         done = dispatch_gemv(M, a, st);
     }
     if (!done && aligned && M <= 64 && K % 32 == 0 && (epi != EPI_SWIGLU || (N / 2) % 16 == 0)) {

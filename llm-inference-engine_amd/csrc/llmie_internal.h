@@ -16,6 +16,15 @@ bool gemv_f16_eligible(int M, int K, const void *x, const void *W);
 int linear_f16_nk_norm(const half_t *x, const half_t *W, half_t *y, int M, int K, int N, int epi, const half_t *bias,
                        const half_t *residual, const half_t *gamma, const half_t *pre_bias, float eps, hipStream_t st);
 
+// quantised-weight (int8 / int4) decode GEMV on the K-split kernel; defined in linear.hip
+struct GemvArgs;
+bool ksplit_eligible(int M, int K, int wbits);
+bool gemv_q_launch(int wbits, int M, const GemvArgs &a, hipStream_t st);
+// weight-only int8/int4 linear with optional fused norm prologue / SwiGLU epilogue (quant_linear.hip)
+int linear_wq(int wbits, const half_t *x, const void *wq, const half_t *scale, half_t *y, int M, int K, int N, int group,
+              int epi, const half_t *bias, const half_t *residual, const half_t *gamma, const half_t *pre_bias, float eps,
+              hipStream_t st);
+
 // decode attention with optional RoPE (rope may be null) fused in front (rope = [max_pos][head_size/2] (cos,sin) table); attention_decode.hip
 int decoder_mha_rope(const void *qkv, const void *qkv_bias, void *k_cache, void *v_cache, void *out, int layer, int batch,
                      int head_num, int kv_head_num, int head_size, int max_seq_len, int step, const int32_t *step_dev,

@@ -7,13 +7,7 @@ using namespace llmie;
 #define PENDING(name) \
     do { set_error(name ": not implemented in this build"); return LLMIE_ERR_UNSUPPORTED; } while (0)
 
-extern "C" int llmie_linear_w8a16(const void *, const int8_t *, const void *, void *, int, int, int, const void *,
-                                  const void *, llmie_stream) { PENDING("linear_w8a16"); }
-extern "C" int llmie_linear_w4a16(const void *, const uint8_t *, const void *, void *, int, int, int, int,
-                                  const void *, const void *, llmie_stream) { PENDING("linear_w4a16"); }
 extern "C" int llmie_linear_fp8(const void *, const uint8_t *, const float *, void *, int, int, int, const void *,
                                 const void *, void *, size_t, llmie_stream) { PENDING("linear_fp8"); }
 extern "C" size_t llmie_linear_fp8_workspace_bytes(int, int) { return 0; }
-extern "C" int llmie_quantize_w8(const void *, int8_t *, void *, int, int, llmie_stream) { PENDING("quantize_w8"); }
-extern "C" int llmie_quantize_w4(const void *, uint8_t *, void *, int, int, int, llmie_stream) { PENDING("quantize_w4"); }
 extern "C" int llmie_quantize_fp8(const void *, uint8_t *, float *, int, int, llmie_stream) { PENDING("quantize_fp8"); }

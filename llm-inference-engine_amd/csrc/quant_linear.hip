@@ -1,0 +1,208 @@
+// Weight-only quantised linears (the reference only plans them: README.md:36-39, linear.cuh:12 TODO):
+//   llmie_linear_w8a16  int8 weights [N,K] + fp16 per-row scale
+//   llmie_linear_w4a16  packed int4 [N,K/2] (low nibble = even k, value = nibble-8) + fp16 scale per (row, group)
+//   llmie_quantize_w8 / _w4  symmetric round-to-nearest quantisers (device side)
+// M <= 8: the K-split streaming GEMV of gemm_kernels.cuh with in-register de-quantisation (bytes per weight
+// halve / quarter, so the HBM-bound decode step speeds up accordingly).  8 < M <= 64: skinny MFMA kernel below:
+// int8 fragments are expanded to fp16 in registers and fed to v_mfma_f32_16x16x32_f16, scale in the epilogue.
+#include "gemm_kernels.cuh"
+#include "llmie_internal.h"
+
+namespace llmie {
+
+// 8 int8 (two words) -> half8 (exact)
+__device__ __forceinline__ half8_t dequant8(unsigned int w0, unsigned int w1) {
+    const half2_t off = {static_cast<half_t>(1152.f), static_cast<half_t>(1152.f)};
+    const unsigned int v0 = w0 ^ 0x80808080u, v1 = w1 ^ 0x80808080u;
+    const half2_t a = as_half2(__builtin_amdgcn_perm(0x64646464u, v0, 0x04010400u)) - off;
+    const half2_t b = as_half2(__builtin_amdgcn_perm(0x64646464u, v0, 0x04030402u)) - off;
+    const half2_t c = as_half2(__builtin_amdgcn_perm(0x64646464u, v1, 0x04010400u)) - off;
+    const half2_t d = as_half2(__builtin_amdgcn_perm(0x64646464u, v1, 0x04030402u)) - off;
+    return half8_t{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+}
+
+// D[n, m] = scale[n] * sum_k Wq[n,k] x[m,k]; one workgroup = one 16-row weight tile, NW waves split K in 64-wide
+// steps (one 16-byte load per lane = 16 consecutive k of one row -> two MFMA A fragments).
+template <int MT, int NW>
+__global__ __launch_bounds__(NW * 64) void skinny_mfma_w8_kernel(const half_t *__restrict__ x,
+                                                                 const int8_t *__restrict__ Wq,
+                                                                 const half_t *__restrict__ scale, half_t *y, int M, int K,
+                                                                 int N, const half_t *__restrict__ bias,
+                                                                 const half_t *residual) {
+    __shared__ floatx4 red[NW][MT][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int nrow = min(blockIdx.x * 16 + r, N - 1);
+    const int8_t *wp = Wq + static_cast<size_t>(nrow) * K + 16 * q;
+    const half_t *xp[MT];
+    bool xok[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        xok[j] = (16 * j + r) < M;
+        xp[j] = x + static_cast<size_t>(xok[j] ? 16 * j + r : 0) * K + 16 * q;
+    }
+    floatx4 acc[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 4;
+    const int ksteps = K >> 6;
+    for (int s0 = wave * U; s0 < ksteps; s0 += NW * U) {
+        uint4_t a[U];
+        half8_t b0[U][MT], b1[U][MT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int s = s0 + u;
+            if (s < ksteps) {
+                a[u] = load_nt(reinterpret_cast<const uint4_t *>(wp + 64 * s));
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    if (xok[j]) {
+                        b0[u][j] = *reinterpret_cast<const half8_t *>(xp[j] + 64 * s);
+                        b1[u][j] = *reinterpret_cast<const half8_t *>(xp[j] + 64 * s + 8);
+                    } else {
+                        b0[u][j] = b1[u][j] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (s0 + u < ksteps) {
+                const half8_t a0 = dequant8(a[u][0], a[u][1]), a1 = dequant8(a[u][2], a[u][3]);
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0[u][j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1[u][j], acc[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MT; ++j) red[wave][j][lane] = acc[j];
+    __syncthreads();
+    for (int j = wave; j < MT; j += NW) {
+        floatx4 s = red[0][j][lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) s += red[w][j][lane];
+        const int m = 16 * j + r;
+        const int n0 = blockIdx.x * 16 + 4 * q;
+        if (m < M) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n0 + e < N) {
+                    float v = s[e] * to_f32(scale[n0 + e]);
+                    if (bias) v += to_f32(bias[n0 + e]);
+                    if (residual) v += to_f32(residual[static_cast<size_t>(m) * N + n0 + e]);
+                    y[static_cast<size_t>(m) * N + n0 + e] = from_f32<half_t>(v);
+                }
+        }
+    }
+}
+
+// ---- quantisers: one workgroup per row (int8) / per (row, group) (int4) ----
+__global__ __launch_bounds__(256) void quantize_w8_kernel(const half_t *__restrict__ w, int8_t *__restrict__ q,
+                                                          half_t *__restrict__ scale, int K) {
+    __shared__ float red[4];
+    const size_t row = blockIdx.x;
+    const half_t *src = w + row * K;
+    float amax = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) amax = fmaxf(amax, fabsf(to_f32(src[k])));
+    amax = block_max<4>(amax, red);
+    half_t sh = from_f32<half_t>(amax / 127.0f);
+    if (to_f32(sh) == 0.f) sh = from_f32<half_t>(1.0f);
+    if (threadIdx.x == 0) scale[row] = sh;
+    const float s = to_f32(sh);
+    for (int k = threadIdx.x; k < K; k += 256) {
+        float v = rintf(to_f32(src[k]) / s);
+        v = fminf(fmaxf(v, -127.f), 127.f);
+        q[row * K + k] = static_cast<int8_t>(v);
+    }
+}
+
+__global__ __launch_bounds__(64) void quantize_w4_kernel(const half_t *__restrict__ w, uint8_t *__restrict__ q,
+                                                         half_t *__restrict__ scale, int K, int group) {
+    const int groups = K / group;
+    const size_t row = blockIdx.x / groups;
+    const int g = blockIdx.x % groups;
+    const half_t *src = w + row * K + static_cast<size_t>(g) * group;
+    float amax = 0.f;
+    for (int k = threadIdx.x; k < group; k += 64) amax = fmaxf(amax, fabsf(to_f32(src[k])));
+    amax = wave_max(amax);
+    half_t sh = from_f32<half_t>(amax / 7.0f);
+    if (to_f32(sh) == 0.f) sh = from_f32<half_t>(1.0f);
+    if (threadIdx.x == 0) scale[row * groups + g] = sh;
+    const float s = to_f32(sh);
+    uint8_t *dst = q + (row * K + static_cast<size_t>(g) * group) / 2;
+    for (int b = threadIdx.x; b < group / 2; b += 64) {
+        float lo = fminf(fmaxf(rintf(to_f32(src[2 * b]) / s), -8.f), 7.f);
+        float hi = fminf(fmaxf(rintf(to_f32(src[2 * b + 1]) / s), -8.f), 7.f);
+        dst[b] = static_cast<uint8_t>((static_cast<int>(lo) + 8) | ((static_cast<int>(hi) + 8) << 4));
+    }
+}
+
+int linear_wq(int wbits, const half_t *x, const void *wq, const half_t *scale, half_t *y, int M, int K, int N, int group,
+              int epi, const half_t *bias, const half_t *residual, const half_t *gamma, const half_t *pre_bias, float eps,
+              hipStream_t st) {
+    const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wq) |
+                           reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(pre_bias)) % 16 == 0) &&
+                         (static_cast<size_t>(K) * wbits / 8) % 16 == 0;
+    if (aligned && ksplit_eligible(M, K, wbits)) {
+        const GemvArgs a{x, wq, y, K, N, bias, residual, gamma, pre_bias, eps, epi, gamma ? 1 : 0, scale, group};
+        if (gemv_q_launch(wbits, M, a, st)) return launch_status("linear_wq");
+    }
+    if (gamma || epi != EPI_NONE) {
+        set_error("linear_wq: fused norm/SwiGLU only on the GEMV path (M=%d K=%d bits=%d)", M, K, wbits);
+        return LLMIE_ERR_UNSUPPORTED;
+    }
+    if (wbits == 8 && aligned && K % 64 == 0 && M <= 64) {
+        const int tiles = (N + 15) / 16;
+        const int mt = (M + 15) / 16;
+        const int8_t *w8 = static_cast<const int8_t *>(wq);
+        switch (mt) {
+            case 1: skinny_mfma_w8_kernel<1, 8><<<tiles, 512, 0, st>>>(x, w8, scale, y, M, K, N, bias, residual); break;
+            case 2: skinny_mfma_w8_kernel<2, 8><<<tiles, 512, 0, st>>>(x, w8, scale, y, M, K, N, bias, residual); break;
+            case 3: skinny_mfma_w8_kernel<3, 8><<<tiles, 512, 0, st>>>(x, w8, scale, y, M, K, N, bias, residual); break;
+            default: skinny_mfma_w8_kernel<4, 8><<<tiles, 512, 0, st>>>(x, w8, scale, y, M, K, N, bias, residual); break;
+        }
+        return launch_status("linear_w8a16");
+    }
+    set_error("linear_wq: unsupported shape M=%d K=%d N=%d bits=%d (int8: M<=64, K%%64==0; int4: M<=8 on the GEMV path)", M, K,
+              N, wbits);
+    return LLMIE_ERR_UNSUPPORTED;
+}
+
+}  // namespace llmie
+
+using namespace llmie;
+
+extern "C" int llmie_linear_w8a16(const void *x, const int8_t *wq, const void *scale, void *y, int M, int K, int N,
+                                  const void *bias, const void *residual, llmie_stream stream) {
+    LLMIE_REQUIRE(x && wq && scale && y, "linear_w8a16: NULL pointer");
+    LLMIE_REQUIRE(M > 0 && K > 0 && N > 0, "linear_w8a16: bad shape");
+    return linear_wq(8, (const half_t *)x, wq, (const half_t *)scale, (half_t *)y, M, K, N, 0, EPI_NONE,
+                     (const half_t *)bias, (const half_t *)residual, nullptr, nullptr, 0.f, as_stream(stream));
+}
+
+extern "C" int llmie_linear_w4a16(const void *x, const uint8_t *wq, const void *scale, void *y, int M, int K, int N,
+                                  int group, const void *bias, const void *residual, llmie_stream stream) {
+    LLMIE_REQUIRE(x && wq && scale && y, "linear_w4a16: NULL pointer");
+    LLMIE_REQUIRE(M > 0 && K > 0 && N > 0, "linear_w4a16: bad shape");
+    LLMIE_REQUIRE(group > 0 && group % 32 == 0 && K % group == 0, "linear_w4a16: group must be a multiple of 32 dividing K");
+    return linear_wq(4, (const half_t *)x, wq, (const half_t *)scale, (half_t *)y, M, K, N, group, EPI_NONE,
+                     (const half_t *)bias, (const half_t *)residual, nullptr, nullptr, 0.f, as_stream(stream));
+}
+
+extern "C" int llmie_quantize_w8(const void *w, int8_t *wq, void *scale, int N, int K, llmie_stream stream) {
+    LLMIE_REQUIRE(w && wq && scale && N > 0 && K > 0, "quantize_w8: bad arguments");
+    quantize_w8_kernel<<<N, 256, 0, as_stream(stream)>>>((const half_t *)w, wq, (half_t *)scale, K);
+    return launch_status("quantize_w8");
+}
+
+extern "C" int llmie_quantize_w4(const void *w, uint8_t *wq, void *scale, int N, int K, int group,
+                                 llmie_stream stream) {
+    LLMIE_REQUIRE(w && wq && scale && N > 0 && K > 0, "quantize_w4: bad arguments");
+    LLMIE_REQUIRE(group > 0 && group % 32 == 0 && K % group == 0, "quantize_w4: group must be a multiple of 32 dividing K");
+    quantize_w4_kernel<<<static_cast<unsigned>(static_cast<size_t>(N) * (K / group)), 64, 0, as_stream(stream)>>>(
+        (const half_t *)w, wq, (half_t *)scale, K, group);
+    return launch_status("quantize_w4");
+}

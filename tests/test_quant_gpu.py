@@ -1,0 +1,138 @@
+"""Weight-only int8 / int4 linears and the quantised decoder engine (new work: the reference only plans
+quantisation, README.md:36-39 -- no reference oracle exists, so the oracle is an fp32 GEMM over the de-quantised
+weights, oracle/llmie_oracle.c orc_linear_w8 / orc_linear_w4, and the quantisers are checked bit-exactly against
+their numpy definition)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+F16 = torch.float16
+
+
+def _h(a):
+    return a.astype(np.float16).astype(np.float32)
+
+
+def _quant8_ref(w):
+    amax = np.abs(w).max(axis=1)
+    s = (amax / np.float32(127.0)).astype(np.float16)
+    s[s == 0] = np.float16(1.0)
+    q = np.clip(np.rint(w / s.astype(np.float32)[:, None]), -127, 127).astype(np.int8)
+    return q, s
+
+
+def _quant4_ref(w, group):
+    N, K = w.shape
+    wg = w.reshape(N, K // group, group)
+    amax = np.abs(wg).max(axis=2)
+    s = (amax / np.float32(7.0)).astype(np.float16)
+    s[s == 0] = np.float16(1.0)
+    q = np.clip(np.rint(wg / s.astype(np.float32)[:, :, None]), -8, 7).astype(np.int32).reshape(N, K) + 8
+    packed = (q[:, 0::2] | (q[:, 1::2] << 4)).astype(np.uint8)
+    return packed, s
+
+
+@pytest.mark.parametrize("N,K", [(256, 4096), (64, 11008), (5, 128)])
+def test_quantizers_bit_exact(llmie, N, K):
+    rng = np.random.default_rng(31)
+    w = _h(rng.standard_normal((N, K)).astype(np.float32) * 0.05)
+    wd = torch.from_numpy(w).to(DEV).to(F16)
+    q8 = torch.empty((N, K), dtype=torch.int8, device=DEV)
+    s8 = torch.empty(N, dtype=F16, device=DEV)
+    llmie.quantize_w8(wd, q8, s8)
+    eq, es = _quant8_ref(w)
+    assert np.array_equal(s8.cpu().numpy(), es) and np.array_equal(q8.cpu().numpy(), eq)
+    group = 128 if K % 128 == 0 else 32
+    q4 = torch.empty((N, K // 2), dtype=torch.uint8, device=DEV)
+    s4 = torch.empty((N, K // group), dtype=F16, device=DEV)
+    llmie.quantize_w4(wd, q4, s4, group)
+    eq4, es4 = _quant4_ref(w, group)
+    assert np.array_equal(s4.cpu().numpy(), es4) and np.array_equal(q4.cpu().numpy(), eq4)
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 4096, 512), (2, 4096, 12288), (4, 4096, 1000), (8, 4096, 512), (1, 11008, 4096),
+                                   (2, 11008, 256), (3, 11008, 256), (8, 11008, 128), (16, 4096, 512), (32, 4096, 1024),
+                                   (33, 11008, 256), (64, 4096, 256), (1, 128, 384)])
+def test_linear_w8a16(llmie, M, K, N):
+    rng = np.random.default_rng(32)
+    w = rng.standard_normal((N, K)).astype(np.float32) / np.sqrt(K)
+    q, s = _quant8_ref(_h(w))
+    x = _h(rng.standard_normal((M, K)).astype(np.float32))
+    y = torch.full((M, N), 9.0, dtype=F16, device=DEV)
+    llmie.linear_w8a16(torch.from_numpy(x).to(DEV).to(F16), torch.from_numpy(q).to(DEV), torch.from_numpy(s).to(DEV), y)
+    exp = orc.linear_w8(x, q, s.astype(np.float32))
+    err = np.abs(y.float().cpu().numpy() - exp)
+    assert (err <= 2e-3 + 2e-3 * np.abs(exp)).all(), err.max()
+
+
+@pytest.mark.parametrize("M,K,N,group", [(1, 4096, 512, 128), (2, 4096, 22016, 128), (4, 4096, 256, 128),
+                                         (1, 11008, 4096, 128), (2, 11008, 128, 128), (1, 128, 64, 32)])
+def test_linear_w4a16(llmie, M, K, N, group):
+    rng = np.random.default_rng(33)
+    w = rng.standard_normal((N, K)).astype(np.float32) / np.sqrt(K)
+    q, s = _quant4_ref(_h(w), group)
+    x = _h(rng.standard_normal((M, K)).astype(np.float32))
+    y = torch.empty((M, N), dtype=F16, device=DEV)
+    llmie.linear_w4a16(torch.from_numpy(x).to(DEV).to(F16), torch.from_numpy(q).to(DEV), torch.from_numpy(s).to(DEV), y, group)
+    exp = orc.linear_w4(x, q, s.astype(np.float32), group)
+    err = np.abs(y.float().cpu().numpy() - exp)
+    assert (err <= 2e-3 + 2e-3 * np.abs(exp)).all(), err.max()
+
+
+def test_linear_w8_fused_bias_residual(llmie):
+    rng = np.random.default_rng(34)
+    M, K, N = 20, 4096, 256
+    q, s = _quant8_ref(_h(rng.standard_normal((N, K)).astype(np.float32) / 64))
+    x, b, r = _h(rng.standard_normal((M, K)).astype(np.float32)), _h(rng.standard_normal(N).astype(np.float32)), \
+        _h(rng.standard_normal((M, N)).astype(np.float32))
+    y = torch.from_numpy(r).to(DEV).to(F16)
+    llmie.linear_w8a16(torch.from_numpy(x).to(DEV).to(F16), torch.from_numpy(q).to(DEV), torch.from_numpy(s).to(DEV), y,
+                       bias=torch.from_numpy(b).to(DEV).to(F16), residual=y)
+    exp = orc.linear_w8(x, q, s.astype(np.float32)) + b[None, :] + r
+    assert np.abs(y.float().cpu().numpy() - exp).max() <= 8e-3
+
+
+@pytest.mark.parametrize("fmt,bs", [("int8", 1), ("int8", 4), ("int8", 20), ("int4", 1), ("int4", 2)])
+def test_quantised_decoder_matches_oracle_on_dequantised_weights(llmie, fmt, bs):
+    rng = np.random.default_rng(35)
+    nh, hs, I, L, max_seq, step, group = 32, 128, 11008, 1, 96, 40, 128
+    H, QKV = nh * hs, 3 * nh * hs
+
+    def mk(n, k):
+        w = _h(rng.uniform(-1, 1, (n, k)).astype(np.float32) * 2 / np.sqrt(k))
+        if fmt == "int8":
+            q, s = _quant8_ref(w)
+            deq = q.astype(np.float32) * s.astype(np.float32)[:, None]
+        else:
+            q, s = _quant4_ref(w, group)
+            lo, hi = (q & 0xF).astype(np.float32) - 8, (q >> 4).astype(np.float32) - 8
+            vals = np.empty((n, k), np.float32)
+            vals[:, 0::2], vals[:, 1::2] = lo, hi
+            deq = vals * np.repeat(s.astype(np.float32), group, axis=1)
+        return dict(data=torch.from_numpy(q).to(DEV), scale=torch.from_numpy(s).to(DEV)), deq
+
+    mats = {k: mk(n, kk) for k, (n, kk) in dict(qkv=(QKV, H), o=(H, H), gate_up=(2 * I, H), down=(H, I)).items()}
+    gam1, gam2 = _h(rng.uniform(0.8, 1.2, H).astype(np.float32)), _h(rng.uniform(0.8, 1.2, H).astype(np.float32))
+    layer = dict(attn_norm=torch.from_numpy(gam1).to(DEV).to(F16), ffn_norm=torch.from_numpy(gam2).to(DEV).to(F16),
+                 **{k: v[0] for k, v in mats.items()})
+    cfg = dict(head_num=nh, kv_head_num=nh, head_size=hs, inter_size=I, num_layers=L, vocab_size=100, max_seq_len=max_seq,
+               max_batch=bs, rotary_dim=hs, rotary_base=10000.0, rms_eps=1e-5, dtype=llmie.F16,
+               wfmt=llmie.W_INT8 if fmt == "int8" else llmie.W_INT4, int4_group=group)
+    dec = llmie.Decoder(cfg, [layer])
+    x = _h(rng.standard_normal((bs, H)).astype(np.float32))
+    kc = _h(rng.standard_normal((L, bs, nh, max_seq, hs)).astype(np.float32) * 0.5)
+    vc = _h(rng.standard_normal((L, bs, nh, max_seq, hs)).astype(np.float32) * 0.5)
+    xd = torch.from_numpy(x).to(DEV).to(F16)
+    out = torch.empty_like(xd)
+    dec.forward(xd, out, torch.from_numpy(kc).to(DEV).to(F16), torch.from_numpy(vc).to(DEV).to(F16), step)
+    olayer = dict(attn_norm=gam1, ffn_norm=gam2, qkv_bias=None, o_bias=None, **{k: v[1] for k, v in mats.items()})
+    ocfg = dict(head_num=nh, kv_head_num=nh, head_size=hs, inter_size=I, num_layers=L, vocab=100, max_seq_len=max_seq,
+                rotary_dim=hs, rotary_base=10000.0, rms_eps=1e-5)
+    exp = orc.self_decoder(ocfg, [olayer], x, kc, vc, step)
+    err = np.abs(out.float().cpu().numpy() - exp)
+    assert (err <= 2e-2 + 2e-2 * np.abs(exp)).all(), err.max()
+    dec.close()
