@@ -44,8 +44,8 @@ def load_llmie():
     return mod
 
 
-def build_model(torch, llmie, cfg, batch, max_seq, seed):
-    """random-init Llama-2 weights of the named architecture, resident in HBM"""
+def build_weights(torch, cfg, seed):
+    """random-init Llama-2 weights of the named architecture (fp16, HF layout), resident in HBM"""
     dev = "cuda"
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
@@ -63,25 +63,50 @@ def build_model(torch, llmie, cfg, batch, max_seq, seed):
         layers.append(dict(attn_norm=torch.ones(H, dtype=torch.float16, device=dev),
                            ffn_norm=torch.ones(H, dtype=torch.float16, device=dev),
                            qkv=w(QKV, H), o=w(H, H), gate_up=w(2 * I, H), down=w(H, I)))
-    model = dict(layers=layers, embed=w(V, H), lm_head=w(V, H),
-                 final_norm=torch.ones(H, dtype=torch.float16, device=dev))
-    kv_shape = (L, batch, cfg["kv_head_num"], max_seq, cfg["head_size"])
-    model["k_cache"] = (torch.randn(kv_shape, generator=g, device=dev, dtype=torch.float32) * 0.5).to(torch.float16)
-    model["v_cache"] = (torch.randn(kv_shape, generator=g, device=dev, dtype=torch.float32) * 0.5).to(torch.float16)
+    return dict(layers=layers, embed=w(V, H), lm_head=w(V, H),
+                final_norm=torch.ones(H, dtype=torch.float16, device=dev), gen=g)
+
+
+def quantize_layers(torch, llmie, layers, wfmt, group=128):
+    """int8 (per-row scale) / int4 (per-group scale) copies of the four big matrices of every layer"""
+    out = []
+    for lw in layers:
+        q = dict(attn_norm=lw["attn_norm"], ffn_norm=lw["ffn_norm"])
+        for name in ("qkv", "o", "gate_up", "down"):
+            w = lw[name]
+            n, k = w.shape
+            if wfmt == "int8":
+                wq = torch.empty((n, k), dtype=torch.int8, device="cuda")
+                sc = torch.empty(n, dtype=torch.float16, device="cuda")
+                llmie.quantize_w8(w, wq, sc)
+            else:
+                wq = torch.empty((n, k // 2), dtype=torch.uint8, device="cuda")
+                sc = torch.empty((n, k // group), dtype=torch.float16, device="cuda")
+                llmie.quantize_w4(w, wq, sc, group)
+            q[name] = dict(data=wq, scale=sc)
+        out.append(q)
+    return out
+
+
+def make_decoder(torch, llmie, cfg, weights, layers, wfmt, batch, max_seq):
+    kv_shape = (cfg["num_layers"], batch, cfg["kv_head_num"], max_seq, cfg["head_size"])
+    g = weights["gen"]
+    kc = (torch.randn(kv_shape, generator=g, device="cuda", dtype=torch.float32) * 0.5).to(torch.float16)
+    vc = (torch.randn(kv_shape, generator=g, device="cuda", dtype=torch.float32) * 0.5).to(torch.float16)
+    fmt = {"f16": llmie.W_F16, "int8": llmie.W_INT8, "int4": llmie.W_INT4}[wfmt]
     ecfg = dict(cfg, max_seq_len=max_seq, max_batch=batch, rotary_dim=cfg["head_size"], rotary_base=10000.0,
-                rms_eps=1e-5, dtype=llmie.F16, wfmt=llmie.W_F16, int4_group=128)
-    model["decoder"] = llmie.Decoder(ecfg, layers)
-    return model
+                rms_eps=1e-5, dtype=llmie.F16, wfmt=fmt, int4_group=128)
+    return llmie.Decoder(ecfg, layers), kc, vc
 
 
-def decode_bytes_per_step(cfg, batch, ctx):
-    """weights once per step + KV read + KV append (fp16 everywhere)"""
+def decode_bytes_per_step(cfg, batch, ctx, wbytes=2.0):
+    """weights once per step (wbytes per element; LM head stays fp16) + KV read + KV append (fp16)"""
     H = cfg["head_num"] * cfg["head_size"]
     KVH = cfg["kv_head_num"] * cfg["head_size"]
     I, L, V = cfg["inter_size"], cfg["num_layers"], cfg["vocab_size"]
-    weights = L * ((H + 2 * KVH) * H + H * H + 3 * H * I) * 2 + V * H * 2
+    weights = L * ((H + 2 * KVH) * H + H * H + 3 * H * I) * wbytes + V * H * 2
     kv = batch * L * 2 * ctx * KVH * 2 + batch * L * 2 * KVH * 2
-    return weights + kv
+    return int(weights + kv)
 
 
 def cpu_baseline(cfg, ctx, budget_s=25.0):
@@ -137,6 +162,7 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="DEBUG ONLY: fewer layers (result marked invalid)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the int8/int4/short-context side measurements")
     args = ap.parse_args()
 
     import torch
@@ -158,74 +184,95 @@ def main():
         cfg["num_layers"] = args.layers
     B, K, W, S = args.batch, args.steps, args.warmup, args.ctx
     H, V = cfg["head_num"] * cfg["head_size"], cfg["vocab_size"]
-    model = build_model(torch, llmie, cfg, B, S, seed=1234 + rank)
-    dec = model["decoder"]
+    weights = build_weights(torch, cfg, seed=1234 + rank)
     dev = "cuda"
     TOPK, BPR = 4, 8
-    ids = torch.randint(0, V, (B,), dtype=torch.int32, device=dev)
-    hidden = torch.empty((B, H), dtype=torch.float16, device=dev)
-    logits = torch.empty((B, V), dtype=torch.float16, device=dev)
-    tmp_ids = torch.empty((B, BPR, TOPK), dtype=torch.int32, device=dev)
-    tmp_vals = torch.empty((B, BPR, TOPK), dtype=torch.float16, device=dev)
-    top_ids = torch.empty((B, TOPK), dtype=torch.int32, device=dev)
-    top_vals = torch.empty((B, TOPK), dtype=torch.float16, device=dev)
-    seq_len = torch.zeros(B, dtype=torch.int32, device=dev)
-    finished = torch.zeros(B, dtype=torch.uint8, device=dev)
-    host_tok = torch.empty(B, dtype=torch.int32, pin_memory=True)
-    total = K + W
-    start_step = max(1, S - total + 1)
-    step_dev = torch.tensor([start_step], dtype=torch.int32, device=dev)
-
-    def one_step():
-        llmie.input_embedding(ids, model["embed"], hidden)
-        dec.forward(hidden, hidden, model["k_cache"], model["v_cache"], -1, step_dev=step_dev)
-        dec.lm_head_sample(hidden, model["final_norm"], model["lm_head"], llmie.W_F16, logits, tmp_ids, tmp_vals,
-                           top_ids, top_vals, seq_len, finished, ids, step=-1, end_id=-1, blocks_per_row=BPR,
-                           step_dev=step_dev)
-        llmie.advance_step(step_dev)
-        host_tok.copy_(ids, non_blocking=True)
-
-    stream = torch.cuda.Stream()
-    graph = None
-    with torch.cuda.stream(stream):
-        one_step()  # eager once (also validates every launch)
-        step_dev.fill_(start_step)
-    stream.synchronize()
-    if not args.no_graph:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=stream):
-            one_step()
-        step_dev.fill_(start_step)
-    torch.cuda.synchronize()
-
-    host_step = [start_step]
-
-    def run(n):
-        with torch.cuda.stream(stream):
-            for _ in range(n):
-                if host_step[0] > S:  # context full: wrap (only when steps+warmup > ctx)
-                    step_dev.fill_(1)
-                    host_step[0] = 1
-                if graph is not None:
-                    graph.replay()
-                else:
-                    one_step()
-                host_step[0] += 1
 
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
 
-    run(W)
-    torch.cuda.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    run(K)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    barrier()
-    elapsed = t1 - t0
+    def run_decode(wfmt, layers, B, S, K, W, profile_steps, sync_ranks):
+        """K timed decode steps ending at context S (hipGraph replay); returns (elapsed_s, profile dict or None)"""
+        dec, kc, vc = make_decoder(torch, llmie, cfg, weights, layers, wfmt, B, S)
+        ids = torch.randint(0, V, (B,), dtype=torch.int32, device=dev)
+        hidden = torch.empty((B, H), dtype=torch.float16, device=dev)
+        logits = torch.empty((B, V), dtype=torch.float16, device=dev)
+        tmp_ids = torch.empty((B, BPR, TOPK), dtype=torch.int32, device=dev)
+        tmp_vals = torch.empty((B, BPR, TOPK), dtype=torch.float16, device=dev)
+        top_ids = torch.empty((B, TOPK), dtype=torch.int32, device=dev)
+        top_vals = torch.empty((B, TOPK), dtype=torch.float16, device=dev)
+        seq_len = torch.zeros(B, dtype=torch.int32, device=dev)
+        finished = torch.zeros(B, dtype=torch.uint8, device=dev)
+        host_tok = torch.empty(B, dtype=torch.int32, pin_memory=True)
+        start_step = max(1, S - (K + W) + 1)
+        step_dev = torch.tensor([start_step], dtype=torch.int32, device=dev)
+
+        def one_step():
+            llmie.input_embedding(ids, weights["embed"], hidden)
+            dec.forward(hidden, hidden, kc, vc, -1, step_dev=step_dev)
+            dec.lm_head_sample(hidden, weights["final_norm"], weights["lm_head"], llmie.W_F16, logits, tmp_ids, tmp_vals,
+                               top_ids, top_vals, seq_len, finished, ids, step=-1, end_id=-1, blocks_per_row=BPR,
+                               step_dev=step_dev)
+            llmie.advance_step(step_dev)
+            host_tok.copy_(ids, non_blocking=True)
+
+        stream = torch.cuda.Stream()
+        graph = None
+        with torch.cuda.stream(stream):
+            one_step()  # eager once (also validates every launch)
+            step_dev.fill_(start_step)
+        stream.synchronize()
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                one_step()
+            step_dev.fill_(start_step)
+        torch.cuda.synchronize()
+        host_step = [start_step]
+
+        def run(n):
+            with torch.cuda.stream(stream):
+                for _ in range(n):
+                    if host_step[0] > S:  # context full: wrap (only when steps+warmup > ctx)
+                        step_dev.fill_(1)
+                        host_step[0] = 1
+                    if graph is not None:
+                        graph.replay()
+                    else:
+                        one_step()
+                    host_step[0] += 1
+
+        run(W)
+        torch.cuda.synchronize()
+        if sync_ranks:
+            barrier()
+        t0 = time.perf_counter()
+        run(K)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        if sync_ranks:
+            barrier()
+        prof = None
+        if profile_steps:
+            # per-kernel timing with hipEvents on the launch stream (eager launches of the same step)
+            P = profile_steps
+            with torch.cuda.stream(stream):
+                step_dev.fill_(max(1, S - P + 1))
+                one_step()  # untimed: re-warm after the fill
+                step_dev.fill_(max(1, S - P + 1))
+                dec.profile_begin(P * (cfg["num_layers"] * 8 + 4))
+                for _ in range(P):
+                    one_step()
+                prof = dec.profile_end()
+        dec.close()
+        del graph, kc, vc
+        torch.cuda.empty_cache()
+        return t1 - t0, prof
+
+    P = 4
+    elapsed, prof = run_decode("f16", weights["layers"], B, S, K, W, P, True)
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -235,16 +282,6 @@ def main():
     value = tokens / elapsed
     ms_per_step = elapsed / K * 1e3
 
-    # ---- per-kernel timing with hipEvents on the launch stream (eager launches of the same step) ----
-    P = 4
-    with torch.cuda.stream(stream):
-        step_dev.fill_(max(1, S - P + 1))
-        one_step()  # untimed: re-warm after the fill
-        step_dev.fill_(max(1, S - P + 1))
-        dec.profile_begin(P * (cfg["num_layers"] * 8 + 4))
-        for _ in range(P):
-            one_step()
-        prof = dec.profile_end()
     breakdown = {op: dict(us_per_launch=round(ms / n * 1e3, 2), launches_per_step=n // P,
                           us_per_step=round(ms / P * 1e3, 1))
                  for op, (ms, n) in prof.items() if n}
@@ -253,7 +290,7 @@ def main():
     gu_ms, gu_n = prof["gate_up_swiglu"]
     gu_us = gu_ms / gu_n * 1e3
     achieved = gu_bytes / (gu_us * 1e-6) / 1e9
-    roofline = dict(bound="hbm", kernel="gemv_ksplit_kernel<M=%d,RPW=8,XC=2> (RMSNorm + gate/up projection + SwiGLU)" % B,
+    roofline = dict(bound="hbm", kernel="gemv_ksplit_kernel<M=%d,RPW=8,XC=2,fp16> (RMSNorm + gate/up projection + SwiGLU)" % B,
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
                     algorithmic_bytes_per_launch=gu_bytes, us_per_launch=round(gu_us, 2), launches_timed=gu_n)
@@ -269,10 +306,34 @@ def main():
         "config": {"workload": "Llama-2-7B 32-layer fp16 decode, batch %d, ctx %d (BASELINE configs[2]); "
                                "random-init weights, synthetic ids, KV pre-filled" % (B, S),
                    "global_batch": world * B, "seq_len": S, "parallelism": "replicas x%d (no collective)" % world,
-                   "graph": graph is not None, "layers": cfg["num_layers"]},
+                   "graph": not args.no_graph, "layers": cfg["num_layers"]},
         "metric_full": "decode tokens/s + prefill tokens/s, Llama-2-7B fp16 & int8, 1 MI355X",
         "roofline": roofline, "whole_step": whole, "breakdown": breakdown,
     }
+    # ---- other configurations of the metric (rank 0, single GPU only; not the headline value) ----
+    if rank == 0 and world == 1 and not args.no_extra:
+        extra = {}
+
+        def record(name, wfmt, layers, b, s, wbytes):
+            k, w_ = min(K, 32), min(W, 4)
+            el, _ = run_decode(wfmt, layers, b, s, k, w_, 0, False)
+            ms = el / k * 1e3
+            nbytes = decode_bytes_per_step(cfg, b, s, wbytes)
+            extra[name] = dict(tokens_per_s=round(b * k / el, 1), ms_per_step=round(ms, 4), batch=b, ctx=s,
+                               algorithmic_GB_per_step=round(nbytes / 1e9, 3),
+                               frac_of_hbm_peak=round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+
+        q8 = quantize_layers(torch, llmie, weights["layers"], "int8")
+        record("decode_int8_b1_ctx2048", "int8", q8, 1, 2048, 1.0)
+        record("decode_int8_b32_ctx128", "int8", q8, 32, 128, 1.0)   # BASELINE configs[3]
+        record("decode_f16_b1_ctx128", "f16", weights["layers"], 1, 128, 2.0)
+        del q8
+        torch.cuda.empty_cache()
+        q4 = quantize_layers(torch, llmie, weights["layers"], "int4")
+        record("decode_int4_b1_ctx2048", "int4", q4, 1, 2048, 0.5 + 2.0 / 128)
+        del q4
+        torch.cuda.empty_cache()
+        out["extra"] = extra
     if args.layers:
         out["config"]["INVALID_debug_layers"] = args.layers
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -281,7 +342,6 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
-    dec.close()
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -27,16 +27,30 @@ template <> struct Vec16<half_t> {
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return static_cast<float>(v); }
 template <typename T> __device__ __forceinline__ T from_f32(float v) { return static_cast<T>(v); }
 
-// ---- wave64 reductions (butterfly over 64 lanes) ----
+// ---- wave64 reductions on DPP (VALU cross-lane moves, no LDS traffic; __shfl_xor lowers to ds_bpermute) ----
+// gfx9 DPP controls: quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140,
+// row_bcast15 = 0x142, row_bcast31 = 0x143.  All 64 lanes must be active at the call.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_or(float v, float masked) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, masked), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_or<0xB1, 0xF>(v, 0.f);
+    v += dpp_or<0x4E, 0xF>(v, 0.f);
+    v += dpp_or<0x141, 0xF>(v, 0.f);
+    v += dpp_or<0x140, 0xF>(v, 0.f);   // every lane: sum of its row of 16
+    v += dpp_or<0x142, 0xA>(v, 0.f);   // rows 1,3 += row 0,2
+    v += dpp_or<0x143, 0xC>(v, 0.f);   // rows 2,3 += (row 0 + row 1): lane 63 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_or<0xB1, 0xF>(v, v));
+    v = fmaxf(v, dpp_or<0x4E, 0xF>(v, v));
+    v = fmaxf(v, dpp_or<0x141, 0xF>(v, v));
+    v = fmaxf(v, dpp_or<0x140, 0xF>(v, v));
+    v = fmaxf(v, dpp_or<0x142, 0xA>(v, v));
+    v = fmaxf(v, dpp_or<0x143, 0xC>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 // reduce within groups of `width` consecutive lanes (width power of two <= 64)
 template <int WIDTH> __device__ __forceinline__ float group_sum(float v) {
