@@ -162,8 +162,10 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
             const uint4_t *w = reinterpret_cast<const uint4_t *>(Wb + static_cast<size_t>(row_of(grp, r)) * row_bytes);
 #pragma unroll
             for (int j = 0; j < XC; ++j) {
-                const int cc = j * 256 + tid;
-                wb[r][j] = cc < nch ? load_nt(w + cc) : uint4_t{0, 0, 0, 0};
+                // unconditional load (a predicated one would put every load in its own exec-masked region); chunks past
+                // the row end re-read the last chunk and meet an all-zero activation slice
+                const int cc = min(j * 256 + tid, nch - 1);
+                wb[r][j] = load_nt(w + cc);
             }
         }
     };
@@ -459,27 +461,27 @@ __global__ __launch_bounds__(NW * 64) void skinny_mfma_f16_kernel(const half_t *
 
     constexpr int U = 4;  // k-steps in flight per wave
     const int ksteps = K >> 5;
+    // all loads unconditional: rows past M read row 0 and k-steps past the end re-read the last step; their B
+    // fragments are zeroed by a select after the load, so no load sits in its own exec-masked region
     for (int s0 = wave * U; s0 < ksteps; s0 += NW * U) {
         half8_t a[U][NT], b[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int s = s0 + u;
-            if (s < ksteps) {
+            const int s = min(s0 + u, ksteps - 1);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) a[u][t] = load_nt(reinterpret_cast<const half8_t *>(wp[t] + 32 * s));
+            for (int t = 0; t < NT; ++t) a[u][t] = load_nt(reinterpret_cast<const half8_t *>(wp[t] + 32 * s));
 #pragma unroll
-                for (int j = 0; j < MT; ++j)
-                    b[u][j] = xok[j] ? *reinterpret_cast<const half8_t *>(xp[j] + 32 * s) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-            }
+            for (int j = 0; j < MT; ++j) b[u][j] = *reinterpret_cast<const half8_t *>(xp[j] + 32 * s);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (s0 + u < ksteps) {
+            const bool live = s0 + u < ksteps;
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const half8_t bz = (live && xok[j]) ? b[u][j] : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int j = 0; j < MT; ++j)
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u][t], b[u][j], acc[t][j], 0, 0, 0);
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u][t], bz, acc[t][j], 0, 0, 0);
             }
         }
     }

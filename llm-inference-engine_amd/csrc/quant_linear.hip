@@ -50,30 +50,24 @@ __global__ __launch_bounds__(NW * 64) void skinny_mfma_w8_kernel(const half_t *_
         uint4_t a[U];
         half8_t b0[U][MT], b1[U][MT];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int s = s0 + u;
-            if (s < ksteps) {
-                a[u] = load_nt(reinterpret_cast<const uint4_t *>(wp + 64 * s));
+        for (int u = 0; u < U; ++u) {  // unconditional loads (clamped step / row 0 for rows past M), zeroed by select below
+            const int s = min(s0 + u, ksteps - 1);
+            a[u] = load_nt(reinterpret_cast<const uint4_t *>(wp + 64 * s));
 #pragma unroll
-                for (int j = 0; j < MT; ++j) {
-                    if (xok[j]) {
-                        b0[u][j] = *reinterpret_cast<const half8_t *>(xp[j] + 64 * s);
-                        b1[u][j] = *reinterpret_cast<const half8_t *>(xp[j] + 64 * s + 8);
-                    } else {
-                        b0[u][j] = b1[u][j] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-                    }
-                }
+            for (int j = 0; j < MT; ++j) {
+                b0[u][j] = *reinterpret_cast<const half8_t *>(xp[j] + 64 * s);
+                b1[u][j] = *reinterpret_cast<const half8_t *>(xp[j] + 64 * s + 8);
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (s0 + u < ksteps) {
-                const half8_t a0 = dequant8(a[u][0], a[u][1]), a1 = dequant8(a[u][2], a[u][3]);
+            const bool live = s0 + u < ksteps;
+            const half8_t a0 = dequant8(a[u][0], a[u][1]), a1 = dequant8(a[u][2], a[u][3]);
 #pragma unroll
-                for (int j = 0; j < MT; ++j) {
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0[u][j], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1[u][j], acc[j], 0, 0, 0);
-                }
+            for (int j = 0; j < MT; ++j) {
+                const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, (live && xok[j]) ? b0[u][j] : z, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, (live && xok[j]) ? b1[u][j] : z, acc[j], 0, 0, 0);
             }
         }
     }

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark through the C ABI (development tool): cycles over NSETS weight copies so every
+launch streams from HBM; reports us per launch (incl. ~1 us launch gap) and effective TB/s."""
+import importlib.util, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("llmie_amd", os.path.join(ROOT, "llm-inference-engine_amd", "__init__.py"))
+llmie = importlib.util.module_from_spec(spec); sys.modules["llmie_amd"] = llmie; spec.loader.exec_module(llmie)
+dev = "cuda"
+NSETS = 12
+
+def timeit(fn, n=NSETS, reps=5):
+    best = 1e9
+    for r in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(n): fn(i)
+        e1.record(); e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / n
+        if r: best = min(best, us)
+    return best
+
+shapes = [("qkv", 12288, 4096), ("o", 4096, 4096), ("gate_up", 22016, 4096), ("down", 4096, 11008)]
+Ms = [int(a) for a in sys.argv[1:]] or [1]
+for M in Ms:
+    for name, N, K in shapes:
+        x = torch.randn((M, K), device=dev).half()
+        y = torch.empty((M, N), device=dev, dtype=torch.float16)
+        W = [(torch.randn((N, K), device=dev) / K ** 0.5).half() for _ in range(NSETS)]
+        t = timeit(lambda i: llmie.linear(x, W[i], y))
+        print("M=%d %-8s f16  %7.2f us  %5.2f TB/s" % (M, name, t, N * K * 2 / t / 1e6))
+        Q = []
+        for w in W:
+            q = torch.empty((N, K), dtype=torch.int8, device=dev); s = torch.empty(N, dtype=torch.float16, device=dev)
+            llmie.quantize_w8(w, q, s); Q.append((q, s))
+        t = timeit(lambda i: llmie.linear_w8a16(x, Q[i][0], Q[i][1], y))
+        print("M=%d %-8s int8 %7.2f us  %5.2f TB/s" % (M, name, t, N * K / t / 1e6))
+        if M <= 2:
+            Q4 = []
+            for w in W:
+                q = torch.empty((N, K // 2), dtype=torch.uint8, device=dev); s = torch.empty((N, K // 128), dtype=torch.float16, device=dev)
+                llmie.quantize_w4(w, q, s, 128); Q4.append((q, s))
+            t = timeit(lambda i: llmie.linear_w4a16(x, Q4[i][0], Q4[i][1], y, 128))
+            print("M=%d %-8s int4 %7.2f us  %5.2f TB/s" % (M, name, t, N * K / 2 / t / 1e6))
+            del Q4
+        del W, Q
+        torch.cuda.empty_cache()
