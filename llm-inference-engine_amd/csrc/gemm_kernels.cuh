@@ -530,6 +530,114 @@ __global__ __launch_bounds__(NW * 64) void skinny_mfma_f16_kernel(const half_t *
 }
 
 // ------------------------------------------------------------------------------------------
+// Tiled MFMA GEMM (prefill / large batches):  C[M,N] = A[M,K] . B[N,K]^T, fp16 in, fp32 accumulate.
+// Both operands are K-contiguous, so every MFMA fragment is one 16-byte LDS read.
+//   block tile 128 x 128, BK = 64, 256 threads = 4 waves as 2 x 2, each wave 64 x 64 = 4 x 4 tiles of
+//   v_mfma_f32_16x16x32_f16 (64 accumulator registers);
+//   LDS: A and B tiles of 128 rows x 128 B, 16-byte chunks XOR-swizzled with (row & 7) so a fragment read
+//   (16 rows x one chunk column) is conflict-free; global -> registers -> LDS with the next k-tile's global
+//   loads issued before the MFMAs of the current one (register double buffering, two barriers per k-tile).
+// Batched through blockIdx.z with dense strides (QK^T of the prefill attention).  MFMA-bound.
+// ------------------------------------------------------------------------------------------
+template <bool HAS_EPI>
+__global__ __launch_bounds__(256) void tiled_mfma_f16_kernel(const half_t *__restrict__ A, const half_t *__restrict__ B,
+                                                             half_t *C, int M, int N, int K, size_t strideA,
+                                                             size_t strideB, size_t strideC,
+                                                             const half_t *__restrict__ bias, const half_t *residual) {
+    constexpr int BM = 128, BN = 128, BK = 64;
+    __shared__ __attribute__((aligned(16))) half_t As[BM * BK];
+    __shared__ __attribute__((aligned(16))) half_t Bs[BN * BK];
+    A += blockIdx.z * strideA;
+    B += blockIdx.z * strideB;
+    C += blockIdx.z * strideC;
+    if (residual) residual += blockIdx.z * strideC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int r = lane & 15, q = lane >> 4;
+
+    // staging: a tile is 128 rows x 8 chunks of 16 B = 1024 chunks, 4 per thread: chunk id = tid + 256*i
+    half8_t ra[4], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+            const int am = min(m0 + row, M - 1), bn = min(n0 + row, N - 1);  // clamp: edge rows are never stored
+            ra[i] = *reinterpret_cast<const half8_t *>(A + static_cast<size_t>(am) * K + k0 + ch * 8);
+            rb[i] = *reinterpret_cast<const half8_t *>(B + static_cast<size_t>(bn) * K + k0 + ch * 8);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+            const int off = row * BK + ((ch ^ (row & 7)) << 3);
+            *reinterpret_cast<half8_t *>(As + off) = ra[i];
+            *reinterpret_cast<half8_t *>(Bs + off) = rb[i];
+        }
+    };
+    floatx4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    gload(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        __syncthreads();  // previous tile fully consumed
+        lstore();
+        __syncthreads();
+        if (k0 + BK < K) gload(k0 + BK);  // in flight under the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {  // two 32-wide k-steps per tile
+            half8_t af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wm * 64 + i * 16 + r;
+                af[i] = *reinterpret_cast<const half8_t *>(As + row * BK + (((ks * 4 + q) ^ (row & 7)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wn * 64 + j * 16 + r;
+                bf[j] = *reinterpret_cast<const half8_t *>(Bs + row * BK + (((ks * 4 + q) ^ (row & 7)) << 3));
+            }
+            // D[n-row, m-col] convention: weights/B as the MFMA A operand gives 4 consecutive n per lane (8-byte stores)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    // acc[i][j]: lane holds C[m = m0 + wm*64 + i*16 + (lane&15)][n = n0 + wn*64 + j*16 + 4*(lane>>4) + e]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + r;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + 4 * q;
+            if (n + 3 < N && !HAS_EPI && (N & 3) == 0) {
+                half4_t o = {from_f32<half_t>(acc[i][j][0]), from_f32<half_t>(acc[i][j][1]), from_f32<half_t>(acc[i][j][2]),
+                             from_f32<half_t>(acc[i][j][3])};
+                *reinterpret_cast<half4_t *>(C + static_cast<size_t>(m) * N + n) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < N) {
+                        float v = acc[i][j][e];
+                        if (HAS_EPI) {
+                            if (bias) v += to_f32(bias[n + e]);
+                            if (residual) v += to_f32(residual[static_cast<size_t>(m) * N + n + e]);
+                        }
+                        C[static_cast<size_t>(m) * N + n + e] = from_f32<half_t>(v);
+                    }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Generic fallback: C[M,N] = A[M,K] * op(B), any T in {float, half}, fp32 accumulate,
 // 64x64 block tile, 16-deep k tile, 256 threads each owning a 4x4 micro tile.
 // Batched via blockIdx.z with dense strides.  B is [N,K] if TRANS_B else [K,N].

@@ -183,13 +183,19 @@ int linear_f16_nk(const half_t *x, const half_t *W, half_t *y, int M, int K, int
         done = (epi == EPI_SWIGLU) ? dispatch_skinny<EPI_SWIGLU>(M, x, W, y, K, N, bias, residual, st)
                                    : dispatch_skinny<EPI_NONE>(M, x, W, y, K, N, bias, residual, st);
     }
-    if (!done) {
-        if (epi == EPI_SWIGLU) {
-            set_error("linear: fused SwiGLU epilogue needs M<=64, K%%32==0, (N/2)%%16==0 (M=%d K=%d N=%d)", M, K, N);
-            return LLMIE_ERR_UNSUPPORTED;
-        }
-        launch_generic<half_t>(x, W, y, 1, M, N, K, true, bias, residual, st);
+    if (!done && epi == EPI_SWIGLU) {
+        set_error("linear: fused SwiGLU epilogue needs M<=64, K%%32==0, (N/2)%%16==0 (M=%d K=%d N=%d)", M, K, N);
+        return LLMIE_ERR_UNSUPPORTED;
     }
+    if (!done && aligned && K % 64 == 0 && reinterpret_cast<uintptr_t>(y) % 8 == 0) {
+        dim3 grid((N + 127) / 128, (M + 127) / 128, 1);
+        if (bias || residual)
+            tiled_mfma_f16_kernel<true><<<grid, 256, 0, st>>>(x, W, y, M, N, K, 0, 0, 0, bias, residual);
+        else
+            tiled_mfma_f16_kernel<false><<<grid, 256, 0, st>>>(x, W, y, M, N, K, 0, 0, 0, nullptr, nullptr);
+        done = true;
+    }
+    if (!done) launch_generic<half_t>(x, W, y, 1, M, N, K, true, bias, residual, st);
     return launch_status("linear");
 }
 
@@ -234,7 +240,14 @@ extern "C" int llmie_batched_gemm(const void *a, const void *b, void *c, int bat
     LLMIE_REQUIRE(batch > 0 && m > 0 && n > 0 && k > 0, "batched_gemm: bad shape");
     LLMIE_REQUIRE(batch <= 65535, "batched_gemm: batch > 65535");
     hipStream_t st = as_stream(stream);
-    if (dtype == LLMIE_F16)
+    if (dtype == LLMIE_F16 && trans_b && k % 64 == 0 && m >= 32 &&
+        ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) % 16 == 0) && reinterpret_cast<uintptr_t>(c) % 8 == 0 &&
+        (static_cast<size_t>(m) * k) % 8 == 0 && (static_cast<size_t>(n) * k) % 8 == 0 && (static_cast<size_t>(m) * n) % 4 == 0) {
+        dim3 grid((n + 127) / 128, (m + 127) / 128, batch);
+        tiled_mfma_f16_kernel<false><<<grid, 256, 0, st>>>((const half_t *)a, (const half_t *)b, (half_t *)c, m, n, k,
+                                                          static_cast<size_t>(m) * k, static_cast<size_t>(n) * k,
+                                                          static_cast<size_t>(m) * n, nullptr, nullptr);
+    } else if (dtype == LLMIE_F16)
         launch_generic<half_t>((const half_t *)a, (const half_t *)b, (half_t *)c, batch, m, n, k, trans_b != 0,
                                nullptr, nullptr, st);
     else if (dtype == LLMIE_F32)

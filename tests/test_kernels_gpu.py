@@ -203,7 +203,8 @@ def test_linear_reference_case_exact(llmie, golden):
     (8, 4096, 1024, True), (8, 11008, 256, True),
     (13, 4096, 1024, True), (16, 4096, 1024, True), (17, 4096, 1000, True), (32, 4096, 2048, True),
     (33, 11008, 512, True), (64, 4096, 512, True),
-    (65, 4096, 256, True), (128, 128, 384, True), (32, 128, 688, True), (32, 344, 128, True),
+    (65, 4096, 256, True), (128, 128, 384, True), (200, 4096, 384, True), (130, 11008, 128, True), (256, 128, 130, True),
+    (2048, 4096, 512, True), (32, 128, 688, True), (32, 344, 128, True),
     (1, 128, 384, True), (7, 100, 37, True), (1, 4096, 4095, True), (3, 4104, 77, True),
     (4, 128, 96, False), (33, 100, 37, False), (128, 512, 256, False)])
 def test_linear(llmie, dtype, M, K, N, trans_b):
@@ -217,7 +218,7 @@ def test_linear(llmie, dtype, M, K, N, trans_b):
     close(host(y), exp, *tol(dtype, f32=(1e-4, 2e-5), f16=(2e-3, 2e-3)))
 
 
-@pytest.mark.parametrize("M", [1, 4, 20])
+@pytest.mark.parametrize("M", [1, 4, 20, 150])
 def test_linear_fused_bias_residual(llmie, M):
     rng = np.random.default_rng(9)
     K, N = 4096, 512

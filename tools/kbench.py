@@ -21,6 +21,16 @@ def timeit(fn, n=NSETS, reps=5):
     return best
 
 shapes = [("qkv", 12288, 4096), ("o", 4096, 4096), ("gate_up", 22016, 4096), ("down", 4096, 11008)]
+if "prefill" in sys.argv:
+    for M in (512, 2048, 4096):
+        for name, N, K in shapes:
+            x = torch.randn((M, K), device=dev).half()
+            y = torch.empty((M, N), device=dev, dtype=torch.float16)
+            W = [(torch.randn((N, K), device=dev) / K ** 0.5).half() for _ in range(4)]
+            t = timeit(lambda i: llmie.linear(x, W[i % 4], y), n=8)
+            print("M=%d %-8s f16 %8.1f us  %6.1f TFLOP/s" % (M, name, t, 2.0 * M * N * K / t / 1e6))
+            del W
+    sys.exit(0)
 Ms = [int(a) for a in sys.argv[1:]] or [1]
 for M in Ms:
     for name, N, K in shapes:
@@ -45,3 +55,7 @@ for M in Ms:
             del Q4
         del W, Q
         torch.cuda.empty_cache()
+
+# ---- prefill GEMM (MFMA-bound): TFLOP/s ----
+if "prefill" in sys.argv:
+    pass
