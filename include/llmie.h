@@ -276,6 +276,17 @@ int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, void *hidde
                           void *k_cache, void *v_cache, int batch, int step,
                           const int32_t *step_dev, llmie_stream stream);
 
+/* Prefill through all layers = LlamaContextDecoder<T>::forward (src/layers/context_decoder.cpp:58-199,
+ * context_attention.cpp:143-312) on PACKED tokens: hidden_in/out [num_tokens, H] hold the sequences back to back
+ * (input_lengths[b] tokens each, device int32), history_lengths[b] tokens of each sequence are already in the caches;
+ * k/v of the new tokens are appended at history+pos.  Attention is a flash kernel: causal mask from the lengths,
+ * no padding buffers, no [bs,nh,q,k] score matrix.  fp16 engines with fp16 weights and head_size 128.
+ * Caches are [L, batch, kvh, max_seq, hs] with the batch of THIS call.  workspace: caller-owned scratch. */
+size_t llmie_decoder_prefill_workspace_bytes(const llmie_decoder_config *cfg, int max_tokens, int max_batch);
+int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, void *hidden_out, void *k_cache, void *v_cache,
+                          const int32_t *input_lengths, const int32_t *history_lengths, int batch, int num_tokens,
+                          int max_q_len, void *workspace, size_t workspace_bytes, llmie_stream stream);
+
 /* LM head + top-k + sampling tail (llama.cpp:247-318): final RMSNorm(gamma) -> logits =
  * x . lm_head[V,H]^T -> top-K -> sample.  logits[bs,V] and topk buffers caller-owned. */
 int llmie_lm_head_sample(llmie_decoder *dec, void *hidden /* [bs,H]; clobbered (may be normalised in place) */,
@@ -293,7 +304,7 @@ int llmie_lm_head_sample(llmie_decoder *dec, void *hidden /* [bs,H]; clobbered (
 enum {
     LLMIE_OP_ATTN_NORM = 0, LLMIE_OP_QKV_GEMM, LLMIE_OP_ROPE, LLMIE_OP_MHA, LLMIE_OP_O_GEMM,
     LLMIE_OP_FFN_NORM, LLMIE_OP_GATE_UP_SWIGLU, LLMIE_OP_DOWN_GEMM, LLMIE_OP_FINAL_NORM,
-    LLMIE_OP_LM_HEAD, LLMIE_OP_TOPK, LLMIE_OP_SAMPLING, LLMIE_OP_COUNT
+    LLMIE_OP_LM_HEAD, LLMIE_OP_TOPK, LLMIE_OP_SAMPLING, LLMIE_OP_COUNT /* prefill re-uses the layer op kinds */
 };
 int llmie_decoder_profile_begin(llmie_decoder *dec, int max_events);
 int llmie_decoder_profile_end(llmie_decoder *dec, llmie_stream stream, double *ms_by_op /*[LLMIE_OP_COUNT]*/,

@@ -71,6 +71,8 @@ _SIGS = {
     "llmie_decoder_create": [_vp, _vp, _vp, _sz],
     "llmie_decoder_destroy": [_vp],
     "llmie_decoder_forward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
+    "llmie_decoder_prefill_workspace_bytes": [_vp, _i, _i],
+    "llmie_decoder_prefill": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp],
     "llmie_lm_head_sample": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp,
                              _i, _vp],
     "llmie_advance_step": [_vp, _vp],
@@ -84,6 +86,7 @@ _RESTYPES = {
     "llmie_decoder_mha_workspace_bytes": _sz,
     "llmie_linear_fp8_workspace_bytes": _sz,
     "llmie_decoder_workspace_bytes": _sz,
+    "llmie_decoder_prefill_workspace_bytes": _sz,
     "llmie_decoder_create": _vp,
     "llmie_decoder_destroy": None,
     "llmie_last_error": C.c_char_p,
@@ -332,6 +335,17 @@ class Decoder:
     def forward(self, hidden_in, hidden_out, k_cache, v_cache, step, step_dev=None):
         _check(lib().llmie_decoder_forward(self.handle, _p(hidden_in), _p(hidden_out), _p(k_cache), _p(v_cache),
                                            hidden_in.shape[0], step, _p(step_dev), _st()), "decoder_forward")
+        return hidden_out
+
+    def prefill(self, hidden_in, hidden_out, k_cache, v_cache, input_lengths, history_lengths, max_q_len):
+        import torch
+        T, bs = hidden_in.shape[0], input_lengths.numel()
+        need = lib().llmie_decoder_prefill_workspace_bytes(C.byref(self.cfg), T, bs)
+        if getattr(self, "_pf_ws", None) is None or self._pf_ws.numel() < need:
+            self._pf_ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+        _check(lib().llmie_decoder_prefill(self.handle, _p(hidden_in), _p(hidden_out), _p(k_cache), _p(v_cache),
+                                           _p(input_lengths), _p(history_lengths), bs, T, max_q_len,
+                                           self._pf_ws.data_ptr(), self._pf_ws.numel(), _st()), "decoder_prefill")
         return hidden_out
 
     def lm_head_sample(self, hidden, final_gamma, lm_head, lm_fmt, logits, tmp_ids, tmp_vals, topk_ids, topk_vals,

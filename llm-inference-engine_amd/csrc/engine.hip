@@ -367,6 +367,78 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
     return LLMIE_OK;
 }
 
+static size_t prefill_carve(const llmie_decoder_config *c, int T, int B, size_t *o /*[7]*/) {
+    const size_t e = 2, H = static_cast<size_t>(c->head_num) * c->head_size;
+    const size_t QKV = static_cast<size_t>(c->head_num + 2 * c->kv_head_num) * c->head_size, I = c->inter_size;
+    Carve k;
+    o[0] = k.take(static_cast<size_t>(T) * H * e);        // residual
+    o[1] = k.take(static_cast<size_t>(T) * QKV * e);      // packed qkv
+    o[2] = k.take(static_cast<size_t>(T) * H * e);        // attention output
+    o[3] = k.take(static_cast<size_t>(T) * 2 * I * e);    // gate_up
+    o[4] = k.take(static_cast<size_t>(T) * I * e);        // act
+    o[5] = k.take(static_cast<size_t>(T) * sizeof(int32_t));        // padding offsets (by-product of the prefix kernel)
+    o[6] = k.take(static_cast<size_t>(B + 1) * sizeof(int32_t));    // cum_seqlens
+    return k.off;
+}
+
+extern "C" size_t llmie_decoder_prefill_workspace_bytes(const llmie_decoder_config *cfg, int max_tokens, int max_batch) {
+    if (!config_ok(cfg) || max_tokens <= 0 || max_batch <= 0) return 0;
+    size_t o[7];
+    return prefill_carve(cfg, max_tokens, max_batch, o);
+}
+
+extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, void *hidden_out, void *k_cache,
+                                     void *v_cache, const int32_t *input_lengths, const int32_t *history_lengths,
+                                     int batch, int num_tokens, int max_q_len, void *workspace, size_t workspace_bytes,
+                                     llmie_stream stream) {
+    LLMIE_REQUIRE(dec && hidden_in && hidden_out && k_cache && v_cache && input_lengths && history_lengths && workspace,
+                  "decoder_prefill: NULL pointer");
+    const llmie_decoder_config &c = dec->cfg;
+    LLMIE_REQUIRE(batch >= 1 && num_tokens >= 1 && max_q_len >= 1 && max_q_len <= num_tokens && max_q_len <= c.max_seq_len,
+                  "decoder_prefill: bad shape batch=%d tokens=%d max_q_len=%d", batch, num_tokens, max_q_len);
+    LLMIE_REQUIRE(num_tokens <= static_cast<long long>(batch) * max_q_len, "decoder_prefill: num_tokens > batch*max_q_len");
+    if (c.dtype != LLMIE_F16 || c.wfmt != LLMIE_W_F16 || c.head_size != 128)
+        LLMIE_UNSUPPORTED("decoder_prefill: fp16 activations + fp16 weights + head_size 128 only (use the per-kernel path)");
+    size_t o[7];
+    const size_t need = prefill_carve(&c, num_tokens, batch, o);
+    if (workspace_bytes < need || reinterpret_cast<uintptr_t>(workspace) % 256) {
+        set_error("decoder_prefill: workspace too small or unaligned (%zu < %zu)", workspace_bytes, need);
+        return LLMIE_ERR_WORKSPACE;
+    }
+    char *base = static_cast<char *>(workspace);
+    half_t *resid = (half_t *)(base + o[0]), *qkv = (half_t *)(base + o[1]), *attn = (half_t *)(base + o[2]);
+    half_t *gu = (half_t *)(base + o[3]), *act = (half_t *)(base + o[4]);
+    int32_t *pad = (int32_t *)(base + o[5]), *cum = (int32_t *)(base + o[6]);
+    const int H = dec->H, QKV = dec->QKV, I = dec->I, T = num_tokens;
+    hipStream_t st = as_stream(stream);
+    int rc;
+    if (hidden_out != hidden_in) {
+        if (hipMemcpyAsync(hidden_out, hidden_in, static_cast<size_t>(T) * H * 2, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            set_error("decoder_prefill: copy failed");
+            return LLMIE_ERR_LAUNCH;
+        }
+    }
+    half_t *h = (half_t *)hidden_out;
+    // context_decoder.cpp:70: exclusive prefix of the lengths (padding offsets are a by-product nobody needs here);
+    // the prefix kernel takes [batch, max_q_len] with max_q_len = ceil(T / batch) rows worth of scratch -> use 1 row of T
+    if ((rc = llmie_cal_padding_offset(pad, cum, input_lengths, batch, (T + batch - 1) / batch, stream))) return rc;
+    for (int l = 0; l < c.num_layers; ++l) {
+        const llmie_layer_weights &w = dec->layers[l];
+        TIMED(LLMIE_OP_ATTN_NORM, llmie_rmsnorm(h, resid, w.attn_norm_gamma, c.rms_eps, T, H, LLMIE_F16, stream));
+        TIMED(LLMIE_OP_QKV_GEMM, linear_f16_nk(h, (const half_t *)w.qkv.data, qkv, T, H, QKV, EPI_NONE_, nullptr, nullptr, st));
+        TIMED(LLMIE_OP_MHA, prefill_attention_f16(qkv, (const half_t *)w.qkv.bias, (half_t *)k_cache, (half_t *)v_cache, attn, cum,
+                                                  history_lengths, dec->rope_table, l, batch, T, max_q_len, c.head_num,
+                                                  c.kv_head_num, c.head_size, c.max_seq_len, c.rotary_dim, st));
+        TIMED(LLMIE_OP_O_GEMM, linear_f16_nk(attn, (const half_t *)w.o.data, h, T, H, H, EPI_NONE_, nullptr, nullptr, st));
+        TIMED(LLMIE_OP_FFN_NORM, llmie_fused_add_bias_residual_rmsnorm(resid, h, w.o.bias, w.ffn_norm_gamma, c.rms_eps, T, H,
+                                                                       LLMIE_F16, stream));
+        TIMED(LLMIE_OP_GATE_UP_SWIGLU, linear_f16_nk(h, (const half_t *)w.gate_up.data, gu, T, H, 2 * I, EPI_NONE_, nullptr, nullptr, st));
+        TIMED(LLMIE_OP_GATE_UP_SWIGLU, llmie_silu_and_mul(gu, act, T, I, LLMIE_F16, stream));
+        TIMED(LLMIE_OP_DOWN_GEMM, linear_f16_nk(act, (const half_t *)w.down.data, h, T, I, H, EPI_NONE_, nullptr, resid, st));
+    }
+    return LLMIE_OK;
+}
+
 extern "C" int llmie_lm_head_sample(llmie_decoder *dec, void *hidden, const void *final_norm_gamma,
                                     const llmie_matrix *lm_head, llmie_weight_format lm_fmt, void *logits,
                                     int32_t *tmp_ids, void *tmp_vals, int32_t *topk_ids, void *topk_vals, int K,

@@ -32,4 +32,10 @@ int decoder_mha_rope(const void *qkv, const void *qkv_bias, void *k_cache, void 
                      int32_t *tickets /* [batch,kvh] zeroed arrival counters: in-launch merge; null = merge kernel */,
                      llmie_dtype dtype, hipStream_t st);
 
+// prefill attention (RoPE + KV append + flash attention) on the packed QKV buffer; prefill.hip
+int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, half_t *k_cache, half_t *v_cache, half_t *out,
+                          const int32_t *cum_seqlens, const int32_t *history_len, const float2 *rope, int layer, int batch,
+                          int num_tokens, int max_q_len, int head_num, int kv_head_num, int head_size, int max_seq_len,
+                          int rotary_dim, hipStream_t st);
+
 }  // namespace llmie

@@ -1,0 +1,114 @@
+"""Prefill (context decoder) engine path: llmie_decoder_prefill (flash attention, packed tokens) against the oracle's
+composition of the reference kernels (context_decoder.cpp:58-199 / context_attention.cpp:143-312), ragged batches with
+history, GQA, several q/k tiles; plus the size-independent property prefill(n+1)[-1] == prefill(n) -> decode(n+1)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV, F16 = "cuda", torch.float16
+
+
+def _h(a):
+    return a.astype(np.float16).astype(np.float32)
+
+
+def _model(rng, nh, kvh, hs, I, L, o_bias=False):
+    H, QKV = nh * hs, (nh + 2 * kvh) * hs
+    u = lambda shape, s: _h(rng.uniform(-1, 1, shape).astype(np.float32) * s)
+    return [dict(attn_norm=_h(u((H,), 0.2) + 1), qkv=u((QKV, H), 2 / np.sqrt(H)), qkv_bias=None, o=u((H, H), 2 / np.sqrt(H)),
+                 o_bias=u((H,), 0.1) if o_bias else None, ffn_norm=_h(u((H,), 0.2) + 1),
+                 gate_up=u((2 * I, H), 2 / np.sqrt(H)), down=u((H, I), 2 / np.sqrt(I))) for _ in range(L)]
+
+
+def _engine(llmie, layers, nh, kvh, hs, I, max_seq, max_batch):
+    d = lambda a: None if a is None else torch.from_numpy(a).to(DEV).to(F16)
+    eng = [dict(attn_norm=d(w["attn_norm"]), ffn_norm=d(w["ffn_norm"]), qkv=dict(data=d(w["qkv"])),
+                o=dict(data=d(w["o"]), bias=d(w["o_bias"])), gate_up=dict(data=d(w["gate_up"])), down=dict(data=d(w["down"])))
+           for w in layers]
+    cfg = dict(head_num=nh, kv_head_num=kvh, head_size=hs, inter_size=I, num_layers=len(layers), vocab_size=100,
+               max_seq_len=max_seq, max_batch=max_batch, rotary_dim=hs, rotary_base=10000.0, rms_eps=1e-5, dtype=llmie.F16,
+               wfmt=llmie.W_F16, int4_group=128)
+    return llmie.Decoder(cfg, eng)
+
+
+def oracle_prefill(layers, x, kc, vc, lens, hist, nh, kvh, hs, I, max_seq):
+    """kc/vc updated in place; returns hidden [T,H]"""
+    bs, T = len(lens), int(sum(lens))
+    mq = int(max(lens))
+    ctx = np.array([l + h for l, h in zip(lens, hist)], np.int32)
+    mk = int(ctx.max())
+    H = nh * hs
+    off, _ = orc.cal_padding_offset(lens, mq, fill=0)
+    off = off.reshape(-1)[:T]
+    mask = orc.build_causal_mask(lens, ctx, mq, mk)
+    h = x.copy()
+    for l, w in enumerate(layers):
+        hn, resid = orc.rmsnorm(h, w["attn_norm"], 1e-5)
+        qkv = orc.linear(hn, w["qkv"]).reshape(T, nh + 2 * kvh, hs)
+        q, k, v = orc.qkv_bias_transpose_rope(qkv, None, off, hist, bs, mq, nh, kvh, hs, hs, 10000.0, fill=0.0)
+        orc.concat_kv(k, kc, lens, hist, l)
+        orc.concat_kv(v, vc, lens, hist, l)
+        kr, vr = orc.repeat_kv(kc, ctx, l, nh, mk), orc.repeat_kv(vc, ctx, l, nh, mk)
+        p = orc.scale_mask_softmax(orc.batched_gemm(q, kr, True), mask, 1.0 / np.sqrt(hs))
+        att = orc.transpose_remove_padding(orc.batched_gemm(p, vr, False), off, T).reshape(T, H)
+        o = orc.linear(att, w["o"])
+        hn2, resid2 = orc.fused_add_bias_residual_rmsnorm(resid, o, w["o_bias"], w["ffn_norm"], 1e-5)
+        act = orc.silu_and_mul(orc.linear(hn2, w["gate_up"]).reshape(T, 2, I))
+        h = orc.add_residual(resid2, orc.linear(act, w["down"]))
+    return h
+
+
+CASES = [("single_40", 8, 8, 1376, 2, [40], [0]), ("ragged_hist", 8, 8, 1376, 2, [70, 5, 33], [0, 10, 64]),
+         ("gqa", 8, 2, 1024, 1, [17, 64], [3, 0]), ("long_300_bias", 8, 8, 512, 1, [300], [20])]
+
+
+@pytest.mark.parametrize("name,nh,kvh,I,L,lens,hist", CASES, ids=[c[0] for c in CASES])
+def test_prefill_matches_oracle(llmie, name, nh, kvh, I, L, lens, hist):
+    rng = np.random.default_rng(41)
+    hs, max_seq = 128, 384
+    H, bs, T = nh * hs, len(lens), int(sum(lens))
+    layers = _model(rng, nh, kvh, hs, I, L, o_bias="bias" in name)
+    dec = _engine(llmie, layers, nh, kvh, hs, I, max_seq, bs)
+    x = _h(rng.standard_normal((T, H)).astype(np.float32))
+    kc = _h(rng.standard_normal((L, bs, kvh, max_seq, hs)).astype(np.float32) * 0.5)
+    vc = _h(rng.standard_normal((L, bs, kvh, max_seq, hs)).astype(np.float32) * 0.5)
+    kd, vd = torch.from_numpy(kc).to(DEV).to(F16), torch.from_numpy(vc).to(DEV).to(F16)
+    xd = torch.from_numpy(x).to(DEV).to(F16)
+    out = torch.empty_like(xd)
+    dec.prefill(xd, out, kd, vd, torch.tensor(lens, dtype=torch.int32, device=DEV),
+                torch.tensor(hist, dtype=torch.int32, device=DEV), max(lens))
+    exp = oracle_prefill(layers, x, kc, vc, np.array(lens, np.int32), np.array(hist, np.int32), nh, kvh, hs, I, max_seq)
+    got = out.float().cpu().numpy()
+    err = np.abs(got - exp)
+    assert (err <= 3e-2 + 3e-2 * np.abs(exp)).all(), "max err %g (|exp| max %g)" % (err.max(), np.abs(exp).max())
+    assert np.abs(kd.float().cpu().numpy() - kc).max() <= 2e-2  # appended rows only differ by rounding; rest untouched
+    dec.close()
+
+
+def test_prefill_then_decode_consistency(llmie):
+    rng = np.random.default_rng(42)
+    nh, hs, I, L, max_seq, n = 8, 128, 1376, 2, 256, 150
+    H = nh * hs
+    layers = _model(rng, nh, nh, hs, I, L)
+    dec = _engine(llmie, layers, nh, nh, hs, I, max_seq, 1)
+    xs = torch.from_numpy(_h(rng.standard_normal((n + 1, H)).astype(np.float32))).to(DEV).to(F16)
+    z = lambda: torch.zeros((L, 1, nh, max_seq, hs), dtype=F16, device=DEV)
+    k1, v1, k2, v2 = z(), z(), z(), z()
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)
+    full = dec.prefill(xs, torch.empty_like(xs), k1, v1, i32([n + 1]), i32([0]), n + 1)
+    dec.prefill(xs[:n].contiguous(), torch.empty((n, H), dtype=F16, device=DEV), k2, v2, i32([n]), i32([0]), n)
+    last = dec.forward(xs[n:n + 1].contiguous(), torch.empty((1, H), dtype=F16, device=DEV), k2, v2, n + 1)
+    a, b = last.float().cpu().numpy(), full[n:n + 1].float().cpu().numpy()
+    assert (np.abs(a - b) <= 2e-2 + 2e-2 * np.abs(b)).all(), np.abs(a - b).max()
+    assert (k1.float() - k2.float()).abs().max().item() <= 2e-2
+    # chunked prefill: 100 tokens, then 51 more on top of the history == one shot
+    k3, v3 = z(), z()
+    dec.prefill(xs[:100].contiguous(), torch.empty((100, H), dtype=F16, device=DEV), k3, v3, i32([100]), i32([0]), 100)
+    part = dec.prefill(xs[100:].contiguous(), torch.empty((n + 1 - 100, H), dtype=F16, device=DEV), k3, v3, i32([n + 1 - 100]),
+                       i32([100]), n + 1 - 100)
+    c, d = part.float().cpu().numpy(), full[100:].float().cpu().numpy()
+    assert (np.abs(c - d) <= 2e-2 + 2e-2 * np.abs(d)).all(), np.abs(c - d).max()
+    dec.close()
