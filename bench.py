@@ -323,6 +323,38 @@ def main():
                                algorithmic_GB_per_step=round(nbytes / 1e9, 3),
                                frac_of_hbm_peak=round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
 
+        def record_prefill(name, b, s):
+            """prefill of b sequences x s tokens (packed), all 32 layers + LM head on the last token of each sequence"""
+            dec, kc, vc = make_decoder(torch, llmie, cfg, weights, weights["layers"], "f16", b, s)
+            T = b * s
+            ids = torch.randint(0, V, (T,), dtype=torch.int32, device=dev)
+            hid = torch.empty((T, H), dtype=torch.float16, device=dev)
+            lens = torch.full((b,), s, dtype=torch.int32, device=dev)
+            hist = torch.zeros(b, dtype=torch.int32, device=dev)
+
+            def once():
+                llmie.input_embedding(ids, weights["embed"], hid)
+                dec.prefill(hid, hid, kc, vc, lens, hist, s)
+
+            once()
+            torch.cuda.synchronize()
+            reps = 3
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                once()
+            torch.cuda.synchronize()
+            el = (time.perf_counter() - t0) / reps
+            Hh, KVH, I_, L_ = H, cfg["kv_head_num"] * cfg["head_size"], cfg["inter_size"], cfg["num_layers"]
+            flops = T * 2.0 * L_ * ((Hh + 2 * KVH) * Hh + Hh * Hh + 3 * Hh * I_) + b * L_ * 4.0 * Hh * s * (s + 1) / 2
+            extra[name] = dict(tokens_per_s=round(T / el, 1), ms=round(el * 1e3, 3), batch=b, seq=s,
+                               TFLOP_per_s=round(flops / el / 1e12, 1), frac_of_mfma_peak=round(flops / el / 2.5e15, 4))
+            dec.close()
+            del kc, vc, hid
+            torch.cuda.empty_cache()
+
+        record_prefill("prefill_f16_b1_s2048", 1, 2048)
+        record_prefill("prefill_f16_b8_s512", 8, 512)
+        record_prefill("prefill_f16_b1_s128", 1, 128)   # BASELINE configs[1] shape (all 32 layers)
         q8 = quantize_layers(torch, llmie, weights["layers"], "int8")
         record("decode_int8_b1_ctx2048", "int8", q8, 1, 2048, 1.0)
         record("decode_int8_b32_ctx128", "int8", q8, 32, 128, 1.0)   # BASELINE configs[3]

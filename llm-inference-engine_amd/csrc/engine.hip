@@ -250,21 +250,14 @@ static int engine_linear(const llmie_decoder *d, llmie_weight_format fmt, const 
             }
             return llmie_linear(x, w.data, y, M, K, N, 1, bias, residual, LLMIE_F32, stream);
         case LLMIE_W_INT8:
-            if (swiglu) {
-                int rc = llmie_linear_w8a16(x, (const int8_t *)w.data, w.scale, d->gu, M, K, N, bias, nullptr, stream);
-                if (rc) return rc;
-                return llmie_silu_and_mul(d->gu, y, M, N / 2, LLMIE_F16, stream);
-            }
-            return llmie_linear_w8a16(x, (const int8_t *)w.data, w.scale, y, M, K, N, bias, residual, stream);
-        case LLMIE_W_INT4:
-            if (swiglu) {
-                int rc = llmie_linear_w4a16(x, (const uint8_t *)w.data, w.scale, d->gu, M, K, N, d->cfg.int4_group, bias,
-                                            nullptr, stream);
-                if (rc) return rc;
-                return llmie_silu_and_mul(d->gu, y, M, N / 2, LLMIE_F16, stream);
-            }
-            return llmie_linear_w4a16(x, (const uint8_t *)w.data, w.scale, y, M, K, N, d->cfg.int4_group, bias, residual,
-                                      stream);
+        case LLMIE_W_INT4: {
+            const int bits = fmt == LLMIE_W_INT8 ? 8 : 4;
+            // GEMV (M <= 8) and split-K MFMA (int8) paths take the SwiGLU epilogue directly
+            int rc = linear_wq(bits, (const half_t *)x, w.data, (const half_t *)w.scale, (half_t *)y, M, K, N, d->cfg.int4_group,
+                               swiglu ? EPI_SWIGLU_ : EPI_NONE_, (const half_t *)bias, (const half_t *)residual, nullptr, nullptr,
+                               0.f, as_stream(stream));
+            return rc;
+        }
         default:
             set_error("engine: weight format %d not supported by this build", (int)fmt);
             return LLMIE_ERR_UNSUPPORTED;

@@ -463,11 +463,16 @@ __global__ __launch_bounds__(NW * 64) void skinny_mfma_f16_kernel(const half_t *
     const int ksteps = K >> 5;
     // all loads unconditional: rows past M read row 0 and k-steps past the end re-read the last step; their B
     // fragments are zeroed by a select after the load, so no load sits in its own exec-masked region
+    // de-phase the workgroups along K: all workgroups start together and advance at the same rate, and a weight
+    // fragment load touches 16 rows that are K*2 bytes apart -- without the rotation every workgroup hits the same
+    // HBM channels at the same time
+    const int rot = (blockIdx.x * 5) % ksteps;
     for (int s0 = wave * U; s0 < ksteps; s0 += NW * U) {
         half8_t a[U][NT], b[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int s = min(s0 + u, ksteps - 1);
+            int s = min(s0 + u, ksteps - 1) + rot;
+            s = s >= ksteps ? s - ksteps : s;
 #pragma unroll
             for (int t = 0; t < NT; ++t) a[u][t] = load_nt(reinterpret_cast<const half8_t *>(wp[t] + 32 * s));
 #pragma unroll
@@ -526,6 +531,166 @@ __global__ __launch_bounds__(NW * 64) void skinny_mfma_f16_kernel(const half_t *
                     }
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Split-K skinny MFMA GEMM for decode batches / short prefills (8 < M <= 64 per pass), fp16 or int8 weights.
+//   Every workgroup must read the activation slice it multiplies, so activation traffic = (#workgroups per full
+//   K sweep) x |x|.  With one 16/32-row tile per workgroup (first skinny kernel above) that is 4x the weight
+//   stream at M = 64 and the kernel is L2-bound (measured 1.6-2.2 TB/s).  Here a workgroup owns 64 weight rows
+//   (one 16-row MFMA tile per wave) x one K slice: its 4 waves read the SAME x fragments (L1 hits after the first),
+//   so L2 activation traffic is (N/64) x |x|, and the grid is filled by splitting K over workgroups (KS slices);
+//   partial tiles go to an fp32 slab [KS][M][N] that skinny_finalize_kernel sums (+ scale, bias, residual, SwiGLU).
+//   A fragment (weights): lane l -> W[n0 + (l&15)][k + 8*(l>>4) .. +8] (int8: 16 consecutive k -> two fragments)
+//   D: lane l holds rows n0 + 4*(l>>4) + {0..3}, column m0 + (l&15) -> 16-byte fp32 stores into the slab.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ half8_t dequant_i8x8(unsigned int w0, unsigned int w1) {
+    const half2_t off = {static_cast<half_t>(1152.f), static_cast<half_t>(1152.f)};
+    const unsigned int v0 = w0 ^ 0x80808080u, v1 = w1 ^ 0x80808080u;
+    const half2_t a = as_half2(__builtin_amdgcn_perm(0x64646464u, v0, 0x04010400u)) - off;
+    const half2_t b = as_half2(__builtin_amdgcn_perm(0x64646464u, v0, 0x04030402u)) - off;
+    const half2_t c = as_half2(__builtin_amdgcn_perm(0x64646464u, v1, 0x04010400u)) - off;
+    const half2_t d = as_half2(__builtin_amdgcn_perm(0x64646464u, v1, 0x04030402u)) - off;
+    return half8_t{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+}
+
+template <int MT, int WBITS>
+__global__ __launch_bounds__(256) void skinny_splitk_kernel(const half_t *__restrict__ x, const void *__restrict__ W,
+                                                            float *__restrict__ slab, int M, int K, int N, int KS,
+                                                            int blocks_per_slice) {
+    // One sub-block = 4 weight loads per lane: fp16 BK = 128 (4 steps of 32), int8 BK = 256 (4 steps of 64).
+    // The activation tile [16*MT rows][BK] of the sub-block is staged in LDS (coalesced 16-byte loads, chunks
+    // XOR-swizzled with the row so a fragment read -- 16 rows x one chunk column -- is conflict-free) and shared by
+    // the 4 waves: B fragments are ds_read_b128 (measured: fragment-shaped global loads of x, even L1-resident,
+    // bound the first versions of this kernel at ~90 cycles per wave-load).  Weight fragments go HBM -> VGPR with
+    // the next sub-block's loads in flight while the current one is multiplied; x tiles are double buffered.
+    constexpr int KSTEP = (WBITS == 16) ? 32 : 64;
+    constexpr int BK = 4 * KSTEP;
+    constexpr int ROWS = 16 * MT;
+    constexpr int CPR = BK / 8;                    // 16-byte chunks per tile row
+    constexpr int XCH = (ROWS * CPR + 255) / 256;  // staging chunks per thread
+    __shared__ __attribute__((aligned(16))) half_t xs[2][ROWS * BK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int tile = blockIdx.x / KS, ks = blockIdx.x - tile * KS;
+    const int n0 = tile * 64 + wave * 16;
+    const int nrow = min(n0 + r, N - 1);
+    const size_t row_bytes = static_cast<size_t>(K) * WBITS / 8;
+    const unsigned char *wp = static_cast<const unsigned char *>(W) + static_cast<size_t>(nrow) * row_bytes + 16 * q;
+    const int nblocks = K / BK;
+    const int b_begin = ks * blocks_per_slice, b_end = min(nblocks, b_begin + blocks_per_slice);
+
+    uint4_t a_cur[4], a_nxt[4];
+    half8_t xr[XCH];
+    auto load_a = [&](int blk, uint4_t(&a)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = load_nt(reinterpret_cast<const uint4_t *>(wp + (static_cast<size_t>(blk) * 4 + u) * 64));
+    };
+    auto load_x = [&](int blk) {
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int id = min(tid + 256 * i, ROWS * CPR - 1), row = id / CPR, ch = id - row * CPR;
+            xr[i] = *reinterpret_cast<const half8_t *>(x + static_cast<size_t>(min(row, M - 1)) * K + static_cast<size_t>(blk) * BK + ch * 8);
+        }
+    };
+    auto store_x = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int id = tid + 256 * i;
+            if (id < ROWS * CPR) {
+                const int row = id / CPR, ch = id - row * CPR;
+                *reinterpret_cast<half8_t *>(&xs[buf][row * BK + ((ch ^ (row & (CPR - 1) & 15)) << 3)]) = xr[i];
+            }
+        }
+    };
+    floatx4 acc[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    if (b_begin < b_end) {
+        load_a(b_begin, a_cur);
+        load_x(b_begin);
+        store_x(0);
+    }
+    __syncthreads();
+    for (int blk = b_begin, it = 0; blk < b_end; ++blk, ++it) {
+        const int buf = it & 1;
+        const bool more = blk + 1 < b_end;
+        if (more) {
+            load_a(blk + 1, a_nxt);
+            load_x(blk + 1);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if constexpr (WBITS == 16) {
+                const half8_t af = __builtin_bit_cast(half8_t, a_cur[u]);
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    const int row = 16 * j + r, ch = u * 4 + q;
+                    const half8_t bf = *reinterpret_cast<const half8_t *>(&xs[buf][row * BK + ((ch ^ (row & 15)) << 3)]);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[j], 0, 0, 0);
+                }
+            } else {
+                const half8_t a0 = dequant_i8x8(a_cur[u][0], a_cur[u][1]), a1 = dequant_i8x8(a_cur[u][2], a_cur[u][3]);
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    const int row = 16 * j + r, ch = u * 8 + 2 * q;  // 16 consecutive k of this lane = chunks ch, ch+1
+                    const half8_t b0 = *reinterpret_cast<const half8_t *>(&xs[buf][row * BK + ((ch ^ (row & 15)) << 3)]);
+                    const half8_t b1 = *reinterpret_cast<const half8_t *>(&xs[buf][row * BK + (((ch + 1) ^ (row & 15)) << 3)]);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, acc[j], 0, 0, 0);
+                }
+            }
+        }
+        if (more) {
+            store_x(buf ^ 1);  // the other buffer was last read in the previous iteration, before its barrier
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a_cur[u] = a_nxt[u];
+        }
+        __syncthreads();
+    }
+    // rows past M were computed on clamped (duplicate) activations: never stored
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int m = 16 * j + r, n = n0 + 4 * q;
+        if (m < M && n < N) {
+            float *dst = slab + (static_cast<size_t>(ks) * M + m) * N + n;
+            if (n + 3 < N && (N & 3) == 0) {
+                *reinterpret_cast<floatx4 *>(dst) = acc[j];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < N) dst[e] = acc[j][e];
+            }
+        }
+    }
+}
+
+// y = sum over the KS slabs (* per-row scale for int8) (+bias)(+residual) | SwiGLU over (n, N/2+n)
+static __global__ __launch_bounds__(256) void skinny_finalize_kernel(const float *__restrict__ slab, half_t *y, int M, int N, int KS,
+                                                              const half_t *__restrict__ scale, const half_t *__restrict__ bias,
+                                                              const half_t *residual, int epi) {
+    const int out_n = epi == EPI_SWIGLU ? N / 2 : N;
+    const size_t total = static_cast<size_t>(M) * out_n;
+    const size_t slab_sz = static_cast<size_t>(M) * N;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * 256) {
+        const int m = static_cast<int>(i / out_n), n = static_cast<int>(i - static_cast<size_t>(m) * out_n);
+        auto gather = [&](int col) {
+            float v = 0.f;
+            for (int k = 0; k < KS; ++k) v += slab[k * slab_sz + static_cast<size_t>(m) * N + col];
+            return scale ? v * to_f32(scale[col]) : v;
+        };
+        float v;
+        if (epi == EPI_SWIGLU) {
+            const float gt = gather(n), up = gather(n + out_n);
+            v = (gt / (1.0f + expf(-gt))) * up;
+        } else {
+            v = gather(n);
+            if (bias) v += to_f32(bias[n]);
+            if (residual) v += to_f32(residual[static_cast<size_t>(m) * N + n]);
+        }
+        y[static_cast<size_t>(m) * out_n + n] = from_f32<half_t>(v);
     }
 }
 

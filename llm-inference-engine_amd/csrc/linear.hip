@@ -151,6 +151,59 @@ static void launch_generic(const T *a, const T *b, T *c, int batch, int M, int N
 // fp16, W[N,K]: the decode / prefill projection path.  epi selects the fused epilogue; a non-null
 // `norm` fuses rmsnorm(x + pre_bias)*gamma in front of the projection (GEMV path only: returns
 // LLMIE_ERR_UNSUPPORTED otherwise so the caller can run the norm as its own kernel).
+// library-owned fp32 scratch for the split-K slabs: grows on first use (warm up once before hipGraph capture)
+static float *splitk_scratch(size_t floats) {
+    static float *buf = nullptr;
+    static size_t cap = 0;
+    if (floats > cap) {
+        if (buf) (void)hipFree(buf);
+        buf = nullptr;
+        cap = 0;
+        if (hipMalloc(reinterpret_cast<void **>(&buf), floats * sizeof(float)) != hipSuccess) return nullptr;
+        cap = floats;
+    }
+    return buf;
+}
+
+// split-K skinny MFMA path: 8 < M (any M, processed 64 rows of x per pass); wbits 16 or 8
+int linear_splitk(int wbits, const half_t *x, const void *W, const half_t *scale, half_t *y, int M, int K, int N, int epi,
+                  const half_t *bias, const half_t *residual, hipStream_t st) {
+    const int bk = wbits == 16 ? 128 : 256;  // k per sub-block (4 weight loads per lane)
+    const int tiles = (N + 63) / 64, total_blocks = K / bk;
+    static const int target = env_int("LLMIE_SPLITK_TARGET_WGS", 512);
+    int KS = 1;
+    while (KS < 16 && tiles * KS < target && total_blocks / (KS * 2) >= 2) KS *= 2;
+    const int spp = (total_blocks + KS - 1) / KS;
+    const int out_n = epi == EPI_SWIGLU ? N / 2 : N;
+    for (int m0 = 0; m0 < M; m0 += 64) {
+        const int mc = M - m0 < 64 ? M - m0 : 64;
+        float *slab = splitk_scratch(static_cast<size_t>(KS) * mc * N);
+        if (!slab) {
+            set_error("linear: split-K scratch allocation failed");
+            return LLMIE_ERR_WORKSPACE;
+        }
+        const half_t *xs = x + static_cast<size_t>(m0) * K;
+        const int mt = (mc + 15) / 16;
+        const dim3 grid(tiles * KS);
+#define LLMIE_SK(MT_)                                                                                          \
+    (wbits == 16 ? skinny_splitk_kernel<MT_, 16><<<grid, 256, 0, st>>>(xs, W, slab, mc, K, N, KS, spp)             \
+                 : skinny_splitk_kernel<MT_, 8><<<grid, 256, 0, st>>>(xs, W, slab, mc, K, N, KS, spp))
+        switch (mt) {
+            case 1: LLMIE_SK(1); break;
+            case 2: LLMIE_SK(2); break;
+            case 3: LLMIE_SK(3); break;
+            default: LLMIE_SK(4); break;
+        }
+#undef LLMIE_SK
+        const size_t total = static_cast<size_t>(mc) * out_n;
+        int fgrid = static_cast<int>((total + 255) / 256);
+        if (fgrid > 2048) fgrid = 2048;
+        skinny_finalize_kernel<<<fgrid, 256, 0, st>>>(slab, y + static_cast<size_t>(m0) * out_n, mc, N, KS, scale, bias,
+                                                      residual ? residual + static_cast<size_t>(m0) * N : nullptr, epi);
+    }
+    return launch_status("linear(split-K)");
+}
+
 // does the GEMV family take (M, K)?  (K-split register budget, else the LDS fallback's 64 KB)
 bool gemv_f16_eligible(int M, int K, const void *x, const void *W) {
     if (K % 8 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) % 16) || M < 1 || M > 8 ||
@@ -179,6 +232,9 @@ int linear_f16_nk(const half_t *x, const half_t *W, half_t *y, int M, int K, int
         const GemvArgs a{x, W, y, K, N, bias, residual, nullptr, nullptr, 0.f, epi, 0, nullptr, 0};
         done = dispatch_gemv(M, a, st);
     }
+    static const int splitk_max_m = env_int("LLMIE_SPLITK_MAX_M", 192);
+    if (!done && aligned && M <= splitk_max_m && K % 128 == 0 && K >= 512 && decode_gemm_mode() != 3)
+        return linear_splitk(16, x, W, nullptr, y, M, K, N, epi, bias, residual, st);
     if (!done && aligned && M <= 64 && K % 32 == 0 && (epi != EPI_SWIGLU || (N / 2) % 16 == 0)) {
         done = (epi == EPI_SWIGLU) ? dispatch_skinny<EPI_SWIGLU>(M, x, W, y, K, N, bias, residual, st)
                                    : dispatch_skinny<EPI_NONE>(M, x, W, y, K, N, bias, residual, st);

@@ -16,6 +16,9 @@ bool gemv_f16_eligible(int M, int K, const void *x, const void *W);
 int linear_f16_nk_norm(const half_t *x, const half_t *W, half_t *y, int M, int K, int N, int epi, const half_t *bias,
                        const half_t *residual, const half_t *gamma, const half_t *pre_bias, float eps, hipStream_t st);
 
+// split-K skinny MFMA GEMM (fp16 or int8 weights), any M processed 64 tokens per pass; epi may be SwiGLU; linear.hip
+int linear_splitk(int wbits, const half_t *x, const void *W, const half_t *scale, half_t *y, int M, int K, int N, int epi,
+                  const half_t *bias, const half_t *residual, hipStream_t st);
 // quantised-weight (int8 / int4) decode GEMV on the K-split kernel; defined in linear.hip
 struct GemvArgs;
 bool ksplit_eligible(int M, int K, int wbits);

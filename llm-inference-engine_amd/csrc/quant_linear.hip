@@ -8,6 +8,8 @@
 #include "gemm_kernels.cuh"
 #include "llmie_internal.h"
 
+#include <cstdlib>
+
 namespace llmie {
 
 // 8 int8 (two words) -> half8 (exact)
@@ -144,8 +146,14 @@ int linear_wq(int wbits, const half_t *x, const void *wq, const half_t *scale, h
         const GemvArgs a{x, wq, y, K, N, bias, residual, gamma, pre_bias, eps, epi, gamma ? 1 : 0, scale, group};
         if (gemv_q_launch(wbits, M, a, st)) return launch_status("linear_wq");
     }
-    if (gamma || epi != EPI_NONE) {
-        set_error("linear_wq: fused norm/SwiGLU only on the GEMV path (M=%d K=%d bits=%d)", M, K, wbits);
+    if (gamma) {
+        set_error("linear_wq: fused norm only on the GEMV path (M=%d K=%d bits=%d)", M, K, wbits);
+        return LLMIE_ERR_UNSUPPORTED;
+    }
+    if (wbits == 8 && aligned && K % 256 == 0 && K >= 512 && !getenv("LLMIE_NO_SPLITK"))
+        return linear_splitk(8, x, wq, scale, y, M, K, N, epi, bias, residual, st);
+    if (epi != EPI_NONE) {
+        set_error("linear_wq: fused SwiGLU needs the GEMV or split-K path (M=%d K=%d bits=%d)", M, K, wbits);
         return LLMIE_ERR_UNSUPPORTED;
     }
     if (wbits == 8 && aligned && K % 64 == 0 && M <= 64) {
