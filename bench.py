@@ -294,6 +294,14 @@ def main():
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
                     algorithmic_bytes_per_launch=gu_bytes, us_per_launch=round(gu_us, 2), launches_timed=gu_n)
+    try:  # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (profiles/), if present
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pm = json.load(f)
+        if B == 1 and not args.layers:
+            roofline["traffic"] = round(pm["hbm_bytes_per_launch"])
+            roofline["traffic_source"] = pm["source"]
+    except (OSError, ValueError, KeyError):
+        pass
     step_bytes = decode_bytes_per_step(cfg, B, S)
     whole = dict(algorithmic_bytes_per_step=step_bytes,
                  achieved_GBs=round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
