@@ -400,3 +400,18 @@ def linear_w4a16(x, wq, scale, y, group, bias=None, residual=None):
     _check(lib().llmie_linear_w4a16(_p(x), _p(wq), _p(scale), _p(y), x.shape[0], x.shape[1], wq.shape[0], group,
                                     _p(bias), _p(residual), _st()), "linear_w4a16")
     return y
+
+
+def quantize_fp8(w, wq, scale):
+    _check(lib().llmie_quantize_fp8(_p(w), _p(wq), _p(scale), w.shape[0], w.shape[1], _st()), "quantize_fp8")
+
+
+def linear_fp8_workspace_bytes(M, K):
+    return lib().llmie_linear_fp8_workspace_bytes(M, K)
+
+
+def linear_fp8(x, wq, wscale, y, workspace, bias=None, residual=None):
+    _check(lib().llmie_linear_fp8(_p(x), _p(wq), _p(wscale), _p(y), x.shape[0], x.shape[1], wq.shape[0], _p(bias),
+                                  _p(residual), _p(workspace), workspace.numel() * workspace.element_size(), _st()),
+           "linear_fp8")
+    return y

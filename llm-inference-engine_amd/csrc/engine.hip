@@ -29,6 +29,8 @@ struct llmie_decoder {
     void *attn_ws;
     size_t attn_ws_bytes;
     float2 *rope_table;  // [max_seq_len][head_size/2] (cos, sin), host-computed at create
+    void *fp8_ws;        // LLMIE_W_FP8 engines: activation quantisation + split-K scratch of llmie_linear_fp8
+    size_t fp8_ws_bytes;
     int32_t *tickets;    // [max_batch, kv_head_num] arrival counters of the in-launch attention merge (zero between launches)
     // profiling (eager only)
     bool profiling = false;
@@ -85,7 +87,7 @@ struct Carve {
     }
 };
 
-static size_t carve(const llmie_decoder_config *c, size_t *offs /*[9]*/) {
+static size_t carve(const llmie_decoder_config *c, size_t *offs /*[10]*/) {
     const size_t e = c->dtype == LLMIE_F16 ? 2 : 4;
     const size_t B = c->max_batch, H = static_cast<size_t>(c->head_num) * c->head_size;
     const size_t QKV = static_cast<size_t>(c->head_num + 2 * c->kv_head_num) * c->head_size;
@@ -100,12 +102,14 @@ static size_t carve(const llmie_decoder_config *c, size_t *offs /*[9]*/) {
     offs[6] = k.take(llmie_decoder_mha_workspace_bytes(c->max_batch, c->head_num, c->head_size, c->max_seq_len));
     offs[7] = k.take(static_cast<size_t>(c->max_seq_len) * (c->head_size / 2) * sizeof(float2));  // RoPE table
     offs[8] = k.take(static_cast<size_t>(c->max_batch) * c->kv_head_num * sizeof(int32_t));         // merge tickets
+    const int kmax = c->inter_size > static_cast<int>(H) ? c->inter_size : static_cast<int>(H);
+    offs[9] = k.take(c->wfmt == LLMIE_W_FP8 ? llmie_linear_fp8_workspace_bytes(c->max_batch, kmax) : 256);
     return k.off;
 }
 
 extern "C" size_t llmie_decoder_workspace_bytes(const llmie_decoder_config *cfg) {
     if (!config_ok(cfg)) return 0;
-    size_t offs[9];
+    size_t offs[10];
     return carve(cfg, offs);
 }
 
@@ -119,7 +123,7 @@ extern "C" llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg, 
         set_error("decoder_create: NULL layers/workspace");
         return nullptr;
     }
-    size_t offs[9];
+    size_t offs[10];
     const size_t need = carve(cfg, offs);
     if (workspace_bytes < need) {
         set_error("decoder_create: workspace too small (%zu < %zu)", workspace_bytes, need);
@@ -160,6 +164,11 @@ extern "C" llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg, 
     d->attn_ws_bytes = llmie_decoder_mha_workspace_bytes(cfg->max_batch, cfg->head_num, cfg->head_size, cfg->max_seq_len);
     d->rope_table = reinterpret_cast<float2 *>(base + offs[7]);
     d->tickets = reinterpret_cast<int32_t *>(base + offs[8]);
+    d->fp8_ws = base + offs[9];
+    {
+        const int kmax = cfg->inter_size > d->H ? cfg->inter_size : d->H;
+        d->fp8_ws_bytes = cfg->wfmt == LLMIE_W_FP8 ? llmie_linear_fp8_workspace_bytes(cfg->max_batch, kmax) : 0;
+    }
     if (hipMemset(d->tickets, 0, static_cast<size_t>(cfg->max_batch) * cfg->kv_head_num * sizeof(int32_t)) != hipSuccess) {
         set_error("decoder_create: ticket memset failed");
         delete d;
@@ -257,6 +266,16 @@ static int engine_linear(const llmie_decoder *d, llmie_weight_format fmt, const 
                                swiglu ? EPI_SWIGLU_ : EPI_NONE_, (const half_t *)bias, (const half_t *)residual, nullptr, nullptr,
                                0.f, as_stream(stream));
             return rc;
+        }
+        case LLMIE_W_FP8: {
+            if (swiglu) {
+                int rc = llmie_linear_fp8(x, (const uint8_t *)w.data, (const float *)w.scale, d->gu, M, K, N, bias, nullptr,
+                                          d->fp8_ws, d->fp8_ws_bytes, stream);
+                if (rc) return rc;
+                return llmie_silu_and_mul(d->gu, y, M, N / 2, LLMIE_F16, stream);
+            }
+            return llmie_linear_fp8(x, (const uint8_t *)w.data, (const float *)w.scale, y, M, K, N, bias, residual, d->fp8_ws,
+                                    d->fp8_ws_bytes, stream);
         }
         default:
             set_error("engine: weight format %d not supported by this build", (int)fmt);

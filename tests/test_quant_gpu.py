@@ -136,3 +136,102 @@ def test_quantised_decoder_matches_oracle_on_dequantised_weights(llmie, fmt, bs)
     err = np.abs(out.float().cpu().numpy() - exp)
     assert (err <= 2e-2 + 2e-2 * np.abs(exp)).all(), err.max()
     dec.close()
+
+
+# --------------------------------------------------------------------------- fp8 (OCP e4m3fn)
+def _e4m3_table():
+    vals = []
+    for b in range(256):
+        s, e, m = b >> 7, (b >> 3) & 0xF, b & 7
+        if e == 15 and m == 7:
+            v = np.nan
+        elif e == 0:
+            v = (m / 8.0) * 2.0 ** -6
+        else:
+            v = (1 + m / 8.0) * 2.0 ** (e - 7)
+        vals.append(-v if s else v)
+    return np.array(vals, np.float32)
+
+
+def _to_e4m3(x):
+    """round-to-nearest-even onto the e4m3fn grid, saturating at +-448; returns (bytes, decoded values)"""
+    tab = _e4m3_table()
+    pos = tab[:127]  # 0 .. 448 ascending (codes 0..126)
+    a = np.minimum(np.abs(x.astype(np.float64)), 448.0)
+    idx = np.clip(np.searchsorted(pos, a), 1, 126)
+    lo, hi = pos[idx - 1].astype(np.float64), pos[idx].astype(np.float64)
+    pick_hi = (a - lo > hi - a) | ((a - lo == hi - a) & (idx % 2 == 0))  # tie -> even code
+    code = np.where(pick_hi, idx, idx - 1).astype(np.uint8)
+    code = np.where(a == 0, 0, code).astype(np.uint8)
+    code = code | (np.signbit(x).astype(np.uint8) << 7)
+    return code, tab[code]
+
+
+def test_quantize_fp8_matches_numpy_e4m3(llmie):
+    rng = np.random.default_rng(51)
+    N, K = 64, 4096
+    w = _h(rng.standard_normal((N, K)).astype(np.float32) * 0.05)
+    q = torch.empty((N, K), dtype=torch.uint8, device=DEV)
+    s = torch.empty(N, dtype=torch.float32, device=DEV)
+    llmie.quantize_fp8(torch.from_numpy(w).to(DEV).to(F16), q, s)
+    es = (np.abs(w).max(axis=1) / np.float32(448.0)).astype(np.float32)
+    assert np.allclose(s.cpu().numpy(), es, rtol=1e-6)
+    code, _ = _to_e4m3(w / es[:, None])
+    got = q.cpu().numpy()
+    mism = (got != code)
+    assert mism.mean() < 1e-3, "fp8 codes differ from the numpy e4m3fn rounding in %.4f%% of elements" % (100 * mism.mean())
+    tab = _e4m3_table()
+    assert np.abs(tab[got] - tab[code]).max() <= 32.0  # a mismatch is at most one ulp at the top binade
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 4096, 512), (8, 4096, 1024), (32, 4096, 12288), (64, 11008, 256), (100, 4096, 256)])
+def test_linear_fp8(llmie, M, K, N):
+    rng = np.random.default_rng(52)
+    w = _h(rng.standard_normal((N, K)).astype(np.float32) / np.sqrt(K))
+    x = _h(rng.standard_normal((M, K)).astype(np.float32))
+    wd = torch.from_numpy(w).to(DEV).to(F16)
+    wq = torch.empty((N, K), dtype=torch.uint8, device=DEV)
+    ws = torch.empty(N, dtype=torch.float32, device=DEV)
+    llmie.quantize_fp8(wd, wq, ws)
+    work = torch.empty(llmie.linear_fp8_workspace_bytes(M, K), dtype=torch.uint8, device=DEV)
+    y = torch.empty((M, N), dtype=F16, device=DEV)
+    llmie.linear_fp8(torch.from_numpy(x).to(DEV).to(F16), wq, ws, y, work)
+    # oracle: fp32 GEMM over the de-quantised operands (device weight codes; numpy e4m3 rounding of the activations)
+    tab = _e4m3_table()
+    wdeq = tab[wq.cpu().numpy()] * ws.cpu().numpy()[:, None]
+    xs = (np.abs(x).max(axis=1) / np.float32(448.0)).astype(np.float32)
+    _, xdeq = _to_e4m3(x / xs[:, None])
+    exp = orc.linear(xdeq * xs[:, None], wdeq)
+    err = np.abs(y.float().cpu().numpy() - exp)
+    # tolerance: fp16 output rounding + rare 1-ulp differences in the on-device activation rounding (ties)
+    assert (err <= 3e-3 + 3e-3 * np.abs(exp)).all(), err.max()
+    # and the fp8 result is close to the fp16 GEMM it approximates (e4m3: 3 mantissa bits on both operands)
+    ref = orc.linear(x, w)
+    assert np.abs(y.float().cpu().numpy() - ref).max() <= 0.12 * np.abs(ref).max()
+
+
+def test_fp8_decoder_runs_and_tracks_fp16(llmie):
+    rng = np.random.default_rng(53)
+    nh, hs, I, L, max_seq, step, bs = 32, 128, 11008, 1, 64, 20, 4
+    H, QKV = nh * hs, 3 * nh * hs
+    mats16, mats8 = {}, {}
+    for k, (n, kk) in dict(qkv=(QKV, H), o=(H, H), gate_up=(2 * I, H), down=(H, I)).items():
+        w = torch.from_numpy(_h(rng.uniform(-1, 1, (n, kk)).astype(np.float32) * 2 / np.sqrt(kk))).to(DEV).to(F16)
+        q = torch.empty((n, kk), dtype=torch.uint8, device=DEV)
+        s = torch.empty(n, dtype=torch.float32, device=DEV)
+        llmie.quantize_fp8(w, q, s)
+        mats16[k], mats8[k] = w, dict(data=q, scale=s)
+    ones = torch.ones(H, dtype=F16, device=DEV)
+    base = dict(head_num=nh, kv_head_num=nh, head_size=hs, inter_size=I, num_layers=L, vocab_size=100, max_seq_len=max_seq,
+                max_batch=bs, rotary_dim=hs, rotary_base=10000.0, rms_eps=1e-5, dtype=llmie.F16, int4_group=128)
+    d16 = llmie.Decoder(dict(base, wfmt=llmie.W_F16), [dict(attn_norm=ones, ffn_norm=ones, **mats16)])
+    d8 = llmie.Decoder(dict(base, wfmt=llmie.W_FP8), [dict(attn_norm=ones, ffn_norm=ones, **mats8)])
+    x = torch.randn((bs, H), device=DEV).to(F16)
+    kc = (torch.randn((L, bs, nh, max_seq, hs), device=DEV) * 0.5).to(F16)
+    vc = (torch.randn((L, bs, nh, max_seq, hs), device=DEV) * 0.5).to(F16)
+    o16 = d16.forward(x, torch.empty_like(x), kc.clone(), vc.clone(), step)
+    o8 = d8.forward(x, torch.empty_like(x), kc.clone(), vc.clone(), step)
+    rel = (o8.float() - o16.float()).norm() / o16.float().norm()
+    assert rel.item() < 0.08, rel.item()
+    d16.close()
+    d8.close()
