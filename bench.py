@@ -68,14 +68,18 @@ def build_weights(torch, cfg, seed):
 
 
 def quantize_layers(torch, llmie, layers, wfmt, group=128):
-    """int8 (per-row scale) / int4 (per-group scale) copies of the four big matrices of every layer"""
+    """int8 (per-row scale) / int4 (per-group scale) / fp8-e4m3 (per-row fp32 scale) copies of the four big matrices"""
     out = []
     for lw in layers:
         q = dict(attn_norm=lw["attn_norm"], ffn_norm=lw["ffn_norm"])
         for name in ("qkv", "o", "gate_up", "down"):
             w = lw[name]
             n, k = w.shape
-            if wfmt == "int8":
+            if wfmt == "fp8":
+                wq = torch.empty((n, k), dtype=torch.uint8, device="cuda")
+                sc = torch.empty(n, dtype=torch.float32, device="cuda")
+                llmie.quantize_fp8(w, wq, sc)
+            elif wfmt == "int8":
                 wq = torch.empty((n, k), dtype=torch.int8, device="cuda")
                 sc = torch.empty(n, dtype=torch.float16, device="cuda")
                 llmie.quantize_w8(w, wq, sc)
@@ -93,7 +97,7 @@ def make_decoder(torch, llmie, cfg, weights, layers, wfmt, batch, max_seq):
     g = weights["gen"]
     kc = (torch.randn(kv_shape, generator=g, device="cuda", dtype=torch.float32) * 0.5).to(torch.float16)
     vc = (torch.randn(kv_shape, generator=g, device="cuda", dtype=torch.float32) * 0.5).to(torch.float16)
-    fmt = {"f16": llmie.W_F16, "int8": llmie.W_INT8, "int4": llmie.W_INT4}[wfmt]
+    fmt = {"f16": llmie.W_F16, "int8": llmie.W_INT8, "int4": llmie.W_INT4, "fp8": llmie.W_FP8}[wfmt]
     ecfg = dict(cfg, max_seq_len=max_seq, max_batch=batch, rotary_dim=cfg["head_size"], rotary_base=10000.0,
                 rms_eps=1e-5, dtype=llmie.F16, wfmt=fmt, int4_group=128)
     return llmie.Decoder(ecfg, layers), kc, vc
@@ -150,6 +154,21 @@ def cpu_baseline(cfg, ctx, budget_s=25.0):
                 sample="oracle (fp32 C restatement of the reference kernels, OpenMP) decode step at ctx %d: "
                        "1 of %d layers timed (median of %d runs: %.3f s) x%d + LM head/top-k/sampling (%.3f s)"
                        % (ctx, cfg["num_layers"], reps, tl, cfg["num_layers"], tm))
+
+
+def replica_aggregate(elapsed_s, tokens_this_rank, world):
+    """Independent data-parallel replicas (no collective on the data path): the job's time is the MAX over
+    ranks, its work the SUM of the per-rank tokens.  torch.distributed (gloo, CPU tensors) is control plane only.
+    Returns (whole_job_tokens_per_s, max_elapsed_s)."""
+    if world <= 1:
+        return tokens_this_rank / elapsed_s, elapsed_s
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([elapsed_s], dtype=torch.float64)
+    n = torch.tensor([float(tokens_this_rank)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(n, op=dist.ReduceOp.SUM)
+    return float(n.item()) / float(t.item()), float(t.item())
 
 
 def main():
@@ -273,13 +292,7 @@ def main():
 
     P = 4
     elapsed, prof = run_decode("f16", weights["layers"], B, S, K, W, P, True)
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    tokens = world * B * K
-    value = tokens / elapsed
+    value, elapsed = replica_aggregate(elapsed, B * K, world)
     ms_per_step = elapsed / K * 1e3
 
     breakdown = {op: dict(us_per_launch=round(ms / n * 1e3, 2), launches_per_step=n // P,
@@ -373,6 +386,13 @@ def main():
         record("decode_int4_b1_ctx2048", "int4", q4, 1, 2048, 0.5 + 2.0 / 128)
         del q4
         torch.cuda.empty_cache()
+        q8f = quantize_layers(torch, llmie, weights["layers"], "fp8")   # BASELINE configs[4]: fp8 batch sweep at ctx 512
+        for b in (1, 32, 128):
+            record("decode_fp8_b%d_ctx512" % b, "fp8", q8f, b, 512, 1.0)
+        del q8f
+        torch.cuda.empty_cache()
+        for b in (32, 128):
+            record("decode_f16_b%d_ctx512" % b, "f16", weights["layers"], b, 512, 2.0)
         out["extra"] = extra
     if args.layers:
         out["config"]["INVALID_debug_layers"] = args.layers
