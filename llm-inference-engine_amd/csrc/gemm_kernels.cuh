@@ -569,38 +569,71 @@ __global__ __launch_bounds__(256) void skinny_splitk_kernel(const half_t *__rest
     constexpr int BK = 4 * KSTEP;
     constexpr int ROWS = 16 * MT;
     constexpr int CPR = BK / 8;                    // 16-byte chunks per tile row
-    constexpr int XCH = (ROWS * CPR + 255) / 256;  // staging chunks per thread
-    __shared__ __attribute__((aligned(16))) half_t xs[2][ROWS * BK];
+    // activation staging group: G sub-blocks at once (all their loads in flight together, one barrier pair per group)
+    // G * ROWS * BK * 2 bytes <= 32 KB of LDS so that 4-5 workgroups stay resident per CU (the whole grid in one round)
+    constexpr int G = (WBITS == 16) ? (MT == 1 ? 8 : (MT == 2 ? 4 : 2)) : (MT == 1 ? 4 : (MT == 2 ? 2 : 1));
+    constexpr int GCH = G * ROWS * CPR;               // 16-byte chunks per group
+    constexpr int XCH = (GCH + 255) / 256;            // staging chunks per thread
+    __shared__ __attribute__((aligned(16))) half_t xs[G][ROWS * BK];
+    // per-wave weight transposer: a sub-block of the wave's 16 rows is 16 x 256 B; it is LOADED row-contiguously
+    // (one wave instruction = 4 rows x 256 B: full cache lines, DRAM-friendly -- fragment-shaped global loads of
+    // 16 rows x 64 B capped this kernel at ~3.8 TB/s) and re-read as MFMA fragments through 4 KB of private LDS.
+    __shared__ __attribute__((aligned(16))) unsigned char wsm[4][16 * 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int tile = blockIdx.x / KS, ks = blockIdx.x - tile * KS;
     const int n0 = tile * 64 + wave * 16;
-    const int nrow = min(n0 + r, N - 1);
     const size_t row_bytes = static_cast<size_t>(K) * WBITS / 8;
-    const unsigned char *wp = static_cast<const unsigned char *>(W) + static_cast<size_t>(nrow) * row_bytes + 16 * q;
+    // load u of a sub-block: lane -> row 4u + (lane >> 4), 16-byte chunk (lane & 15)
+    const unsigned char *wp = static_cast<const unsigned char *>(W) + 16 * r;
+    size_t wrow_off[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wrow_off[u] = static_cast<size_t>(min(n0 + 4 * u + q, N - 1)) * row_bytes;
     const int nblocks = K / BK;
     const int b_begin = ks * blocks_per_slice, b_end = min(nblocks, b_begin + blocks_per_slice);
 
-    uint4_t a_cur[4], a_nxt[4];
+    // weight fragments: ring of 4 sub-blocks (16 loads in flight per lane), refilled as soon as a slot is consumed
+    constexpr int R = G < 4 ? G : 4;  // ring depth (G % R == 0 so slot indices stay compile-time)
+    uint4_t a[R][4];
     half8_t xr[XCH];
-    auto load_a = [&](int blk, uint4_t(&a)[4]) {
+    auto load_a = [&](int blk, uint4_t(&dst)[4]) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] = load_nt(reinterpret_cast<const uint4_t *>(wp + (static_cast<size_t>(blk) * 4 + u) * 64));
+        for (int u = 0; u < 4; ++u) dst[u] = load_nt(reinterpret_cast<const uint4_t *>(wp + wrow_off[u] + static_cast<size_t>(blk) * 256));
     };
-    auto load_x = [&](int blk) {
+    unsigned char *wmine = &wsm[wave][0];
+    // registers (row-contiguous image) -> LDS -> MFMA fragments; same-wave LDS ops execute in order, the fences only
+    // stop the compiler from reordering them
+    auto transpose_w = [&](const uint4_t(&src)[4], uint4_t(&frag)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = 4 * u + q;
+            *reinterpret_cast<uint4_t *>(wmine + row * 256 + ((r ^ (row & 15)) << 4)) = src[u];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int u = 0; u < 4; ++u) frag[u] = *reinterpret_cast<const uint4_t *>(wmine + r * 256 + (((4 * u + q) ^ (r & 15)) << 4));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // group staging: chunk id -> (sub-block g, row, chunk); sub-blocks past the slice end re-read the last one (unused)
+    auto load_xg = [&](int blk0, int last_blk) {
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
-            const int id = min(tid + 256 * i, ROWS * CPR - 1), row = id / CPR, ch = id - row * CPR;
+            const int id = min(tid + 256 * i, GCH - 1);
+            const int g = id / (ROWS * CPR), rem = id - g * (ROWS * CPR), row = rem / CPR, ch = rem - row * CPR;
+            const int blk = min(blk0 + g, last_blk);
             xr[i] = *reinterpret_cast<const half8_t *>(x + static_cast<size_t>(min(row, M - 1)) * K + static_cast<size_t>(blk) * BK + ch * 8);
         }
     };
-    auto store_x = [&](int buf) {
+    auto store_xg = [&]() {
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
             const int id = tid + 256 * i;
-            if (id < ROWS * CPR) {
-                const int row = id / CPR, ch = id - row * CPR;
-                *reinterpret_cast<half8_t *>(&xs[buf][row * BK + ((ch ^ (row & (CPR - 1) & 15)) << 3)]) = xr[i];
+            if (id < GCH) {
+                const int g = id / (ROWS * CPR), rem = id - g * (ROWS * CPR), row = rem / CPR, ch = rem - row * CPR;
+                *reinterpret_cast<half8_t *>(&xs[g][row * BK + ((ch ^ (row & 15)) << 3)]) = xr[i];
             }
         }
     };
@@ -608,23 +641,11 @@ __global__ __launch_bounds__(256) void skinny_splitk_kernel(const half_t *__rest
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    if (b_begin < b_end) {
-        load_a(b_begin, a_cur);
-        load_x(b_begin);
-        store_x(0);
-    }
-    __syncthreads();
-    for (int blk = b_begin, it = 0; blk < b_end; ++blk, ++it) {
-        const int buf = it & 1;
-        const bool more = blk + 1 < b_end;
-        if (more) {
-            load_a(blk + 1, a_nxt);
-            load_x(blk + 1);
-        }
+    auto compute = [&](const uint4_t(&ab)[4], int buf) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if constexpr (WBITS == 16) {
-                const half8_t af = __builtin_bit_cast(half8_t, a_cur[u]);
+                const half8_t af = __builtin_bit_cast(half8_t, ab[u]);
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {
                     const int row = 16 * j + r, ch = u * 4 + q;
@@ -632,7 +653,7 @@ __global__ __launch_bounds__(256) void skinny_splitk_kernel(const half_t *__rest
                     acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[j], 0, 0, 0);
                 }
             } else {
-                const half8_t a0 = dequant_i8x8(a_cur[u][0], a_cur[u][1]), a1 = dequant_i8x8(a_cur[u][2], a_cur[u][3]);
+                const half8_t a0 = dequant_i8x8(ab[u][0], ab[u][1]), a1 = dequant_i8x8(ab[u][2], ab[u][3]);
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {
                     const int row = 16 * j + r, ch = u * 8 + 2 * q;  // 16 consecutive k of this lane = chunks ch, ch+1
@@ -643,12 +664,28 @@ __global__ __launch_bounds__(256) void skinny_splitk_kernel(const half_t *__rest
                 }
             }
         }
-        if (more) {
-            store_x(buf ^ 1);  // the other buffer was last read in the previous iteration, before its barrier
+    };
+    const int nb = max(0, b_end - b_begin);
+    if (nb > 0) load_xg(b_begin, b_end - 1);  // activations first (L2), then the weight ring (HBM)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) a_cur[u] = a_nxt[u];
-        }
+    for (int i = 0; i < R; ++i)
+        if (i < nb) load_a(b_begin + i, a[i]);
+    static_assert(G % R == 0, "group size vs ring depth");
+    for (int g0 = 0; g0 < nb; g0 += G) {
+        store_xg();
         __syncthreads();
+        if (g0 + G < nb) load_xg(b_begin + g0 + G, b_end - 1);  // next group's activations in flight under the MFMAs
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int b = g0 + i;  // wave-uniform
+            if (b < nb) {
+                uint4_t frag[4];
+                transpose_w(a[i % R], frag);
+                if (b + R < nb) load_a(b_begin + b + R, a[i % R]);  // ring slot free again
+                compute(frag, i);
+            }
+        }
+        __syncthreads();  // group consumed before the next store_xg overwrites it
     }
     // rows past M were computed on clamped (duplicate) activations: never stored
 #pragma unroll

@@ -171,8 +171,10 @@ int linear_splitk(int wbits, const half_t *x, const void *W, const half_t *scale
     const int bk = wbits == 16 ? 128 : 256;  // k per sub-block (4 weight loads per lane)
     const int tiles = (N + 63) / 64, total_blocks = K / bk;
     static const int target = env_int("LLMIE_SPLITK_TARGET_WGS", 512);
+    // K slices: enough workgroups to fill the chip, but >= 4 sub-blocks per slice (the weight ring depth) and as few
+    // slabs as possible (slab traffic = 2 * KS * M * N * 4 bytes)
     int KS = 1;
-    while (KS < 16 && tiles * KS < target && total_blocks / (KS * 2) >= 2) KS *= 2;
+    while (KS < 16 && tiles * KS < target && total_blocks / (KS * 2) >= 4) KS *= 2;
     const int spp = (total_blocks + KS - 1) / KS;
     const int out_n = epi == EPI_SWIGLU ? N / 2 : N;
     for (int m0 = 0; m0 < M; m0 += 64) {
