@@ -81,16 +81,24 @@ __device__ __forceinline__ float chunk_dot(const uint4_t w, const half8_t (&x)[W
         }
         return acc;
     } else {
-        // word i holds k = 8i..8i+7 as nibbles n0..n7; (w >> 4s) & 0x000F000F = (n_s, n_{s+4}) -> 1024 + n; value = n - 8
+        // word i holds k = 8i..8i+7 as nibbles n0..n7.  (w & 0x000F000F)|0x6400.. = (1024+n0, 1024+n4); the nibbles at
+        // bits 4-7 land 4 mantissa bits higher: (w & 0x00F000F0)|0x6400.. = (1024+16 n1, 1024+16 n5), brought back with
+        // one packed fma (x/16 - 72 = n - 8, exact); one shift by 8 exposes n2,n6 / n3,n7 to the same two masks.
         const half2_t off = {static_cast<half_t>(1032.f), static_cast<half_t>(1032.f)};
+        const half2_t sixteenth = {static_cast<half_t>(0.0625f), static_cast<half_t>(0.0625f)};
+        const half2_t off72 = {static_cast<half_t>(72.f), static_cast<half_t>(72.f)};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const half8_t xv = x[i];  // permuted: (k0,k4,k1,k5,k2,k6,k3,k7) of this word
-#pragma unroll
-            for (int sft = 0; sft < 4; ++sft) {
-                const unsigned int u = ((w[i] >> (4 * sft)) & 0x000F000Fu) | 0x64006400u;
-                acc = __builtin_amdgcn_fdot2(as_half2(u) - off, half2_t{xv[2 * sft], xv[2 * sft + 1]}, acc, false);
-            }
+            const unsigned int w0 = w[i], w8 = w[i] >> 8;
+            const half2_t h0 = as_half2((w0 & 0x000F000Fu) | 0x64006400u) - off;
+            const half2_t h1 = as_half2((w0 & 0x00F000F0u) | 0x64006400u) * sixteenth - off72;
+            const half2_t h2 = as_half2((w8 & 0x000F000Fu) | 0x64006400u) - off;
+            const half2_t h3 = as_half2((w8 & 0x00F000F0u) | 0x64006400u) * sixteenth - off72;
+            acc = __builtin_amdgcn_fdot2(h0, half2_t{xv[0], xv[1]}, acc, false);
+            acc = __builtin_amdgcn_fdot2(h1, half2_t{xv[2], xv[3]}, acc, false);
+            acc = __builtin_amdgcn_fdot2(h2, half2_t{xv[4], xv[5]}, acc, false);
+            acc = __builtin_amdgcn_fdot2(h3, half2_t{xv[6], xv[7]}, acc, false);
         }
         return acc;
     }
@@ -109,8 +117,10 @@ __device__ __forceinline__ half8_t permute_x_int4(const half8_t v) {
 // add their partial sums through a double-buffered LDS slot.
 // Measured fp16 (tools/gemv_bench.hip, MI355X, incl. ~1 us launch gap): QKV 100.7 MB 16.7 us, O 33.6 MB
 // 7.6 us, down 90.2 MB 16.1 us, LM head 262 MB 42 us = 6.0 / 4.4 / 5.6 / 6.2 TB/s.
-template <int M, int RPW, int XC, int WBITS>
+template <int M, int RPW, int XC, int WBITS, bool DB = false>
 __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
+    // DB (quantised weights): two weight register sets -- the next group's loads are issued BEFORE the current group's
+    // de-quantise + dot phase (~2 us of VALU per group for int4), which would otherwise run with nothing in flight.
     static_assert(RPW % 2 == 0, "rows come in pairs");
     constexpr int XE = WFmt<WBITS>::XE;   // half8 activations per weight chunk
     constexpr int EPC = 8 * XE;           // weights per 16-byte chunk
@@ -154,12 +164,23 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
             for (int e = 0; e < XE; ++e) g[j][e] = cc < nch ? gm[cc * XE + e] : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
-    uint4_t wb[RPW][XC];
+    constexpr int SR = WBITS == 4 ? RPW : 1, SX = WBITS == 4 ? XC : 1;
+    uint4_t wbA[RPW][XC], wbB[DB ? RPW : 1][DB ? XC : 1];
+    half_t wscA[SR][SX], wscB[DB ? SR : 1][DB ? SX : 1];  // int4: per-(row, k-group) scales, loaded with the weights
     const unsigned char *Wb = reinterpret_cast<const unsigned char *>(a.W);
-    auto load_group = [&](int grp) {
+    const half_t *scale = reinterpret_cast<const half_t *>(a.scale);
+    const int sgroups = (WBITS == 4) ? K / a.group : 1;  // scales per row
+    auto load_group = [&](int grp, auto &wb, auto &wsc) {
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const uint4_t *w = reinterpret_cast<const uint4_t *>(Wb + static_cast<size_t>(row_of(grp, r)) * row_bytes);
+            if constexpr (WBITS == 4) {
+                // a 32-weight chunk lies inside one scale group (group % 32 == 0); issued with the weight loads so
+                // the scale's L2 round trip overlaps the HBM one instead of following it
+                const half_t *srow = scale + static_cast<size_t>(row_of(grp, r)) * sgroups;
+#pragma unroll
+                for (int j = 0; j < XC; ++j) wsc[r][j] = srow[(min(j * 256 + tid, nch - 1) * EPC) / a.group];
+            }
 #pragma unroll
             for (int j = 0; j < XC; ++j) {
                 // unconditional load (a predicated one would put every load in its own exec-masked region); chunks past
@@ -170,7 +191,7 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
         }
     };
     int grp = blockIdx.x;
-    if (grp < ngroups) load_group(grp);  // in flight while the norm below waits only for x / gamma
+    if (grp < ngroups) load_group(grp, wbA, wscA);  // in flight while the norm below waits only for x / gamma
 
     if (a.norm) {
         const half8_t *pb = reinterpret_cast<const half8_t *>(a.pre_bias);
@@ -221,22 +242,19 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
 #pragma unroll
                 for (int e = 0; e < XE; ++e) xr[m][j][e] = permute_x_int4(xr[m][j][e]);
     }
-    const half_t *scale = reinterpret_cast<const half_t *>(a.scale);
-    const int sgroups = (WBITS == 4) ? K / a.group : 1;  // scales per row
 
-    for (int it = 0; grp < ngroups; ++it) {
+    auto step = [&](auto &wb, auto &wsc, auto &wbn, auto &wscn, const int cur, const int it) {
+        const int nxt = cur + gridDim.x;
+        if constexpr (DB) {
+            if (nxt < ngroups) load_group(nxt, wbn, wscn);
+        }
         float acc[M][RPW];
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             float sc[XC];
             if constexpr (WBITS == 4) {
-                // one scale per (row, k-group); a 32-weight chunk lies inside one group (group % 32 == 0)
-                const half_t *srow = scale + static_cast<size_t>(row_of(grp, r)) * sgroups;
 #pragma unroll
-                for (int j = 0; j < XC; ++j) {
-                    const int cc = j * 256 + tid;
-                    sc[j] = cc < nch ? to_f32(srow[(cc * EPC) / a.group]) : 0.f;
-                }
+                for (int j = 0; j < XC; ++j) sc[j] = to_f32(wsc[r][j]);  // out-of-range chunks meet zero activations
             }
 #pragma unroll
             for (int m = 0; m < M; ++m) {
@@ -249,10 +267,10 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
                 acc[m][r] = sdot;
             }
         }
-        // the weight registers are dead now: put the next group's loads in flight before the reduction/barrier
-        const int cur = grp;
-        grp += gridDim.x;
-        if (grp < ngroups) load_group(grp);
+        // single buffer: the weight registers are dead now -- next group's loads go out before the reduction/barrier
+        if constexpr (!DB) {
+            if (nxt < ngroups) load_group(nxt, wb, wsc);
+        }
 #pragma unroll
         for (int r = 0; r < RPW; ++r)
 #pragma unroll
@@ -295,6 +313,18 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
                     if (a.residual) v += to_f32(a.residual[static_cast<size_t>(m) * N + col]);
                     a.y[static_cast<size_t>(m) * N + col] = from_f32<half_t>(v);
                 }
+            }
+        }
+    };
+    for (int it = 0; grp < ngroups;) {
+        step(wbA, wscA, wbB, wscB, grp, it);
+        grp += gridDim.x;
+        ++it;
+        if constexpr (DB) {
+            if (grp < ngroups) {
+                step(wbB, wscB, wbA, wscA, grp, it);
+                grp += gridDim.x;
+                ++it;
             }
         }
     }

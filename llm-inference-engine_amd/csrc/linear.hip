@@ -20,14 +20,14 @@ static int decode_gemm_mode() {
 // ---- decode GEMV dispatch ----
 // K-split kernel: XC = 16-byte chunks per thread = ceil(K*WBITS/128/256) rounded up to {1,2,3,4,6,8}; RPW rows per
 // iteration so that RPW*XC ~ 16 loads are in flight per lane; register budget M*XC*XE <= 16 half8 of activations.
-template <int M, int RPW, int XC, int WBITS> static void launch_ksplit(const GemvArgs &a, hipStream_t st) {
+template <int M, int RPW, int XC, int WBITS, bool DB = false> static void launch_ksplit(const GemvArgs &a, hipStream_t st) {
     const bool swiglu = a.epi == EPI_SWIGLU;
     const int groups = swiglu ? (a.N / 2 + RPW / 2 - 1) / (RPW / 2) : (a.N + RPW - 1) / RPW;
     // long-lived workgroups (the prologue -- activation slice + norm -- is paid once per workgroup), evenly loaded
     static const int target = env_int("LLMIE_GEMV_TARGET_WGS", 768);
     const int iters = (groups + target - 1) / target;
     const int grid = (groups + iters - 1) / iters;
-    gemv_ksplit_kernel<M, RPW, XC, WBITS><<<grid, 256, 0, st>>>(a);
+    gemv_ksplit_kernel<M, RPW, XC, WBITS, DB><<<grid, 256, 0, st>>>(a);
 }
 
 static int ksplit_xc(int K, int wbits) { return (K * wbits / 128 + 255) / 256; }
@@ -36,13 +36,21 @@ template <int M, int WBITS> static bool dispatch_ksplit(const GemvArgs &a, hipSt
     constexpr int XE = WFmt<WBITS>::XE;
     const int xc = ksplit_xc(a.K, WBITS);
     if constexpr (M * 1 * XE <= 16) {
-        if (xc <= 1) { launch_ksplit<M, (WBITS == 16 ? 8 : 16), 1, WBITS>(a, st); return true; }
+        if (xc <= 1) {  // quantised rows are short: 8 rows per group, double buffered (16 loads in flight per lane)
+            if constexpr (WBITS == 16) launch_ksplit<M, 8, 1, 16>(a, st);
+            else launch_ksplit<M, 8, 1, WBITS, true>(a, st);
+            return true;
+        }
     }
     if constexpr (M * 2 * XE <= 16) {
-        if (xc <= 2) { launch_ksplit<M, 8, 2, WBITS>(a, st); return true; }
+        if (xc <= 2) {
+            if constexpr (WBITS == 16) launch_ksplit<M, 8, 2, 16>(a, st);
+            else launch_ksplit<M, 4, 2, WBITS, true>(a, st);
+            return true;
+        }
     }
     if constexpr (M * 3 * XE <= 16 && WBITS != 16) {
-        if (xc <= 3) { launch_ksplit<M, 4, 3, WBITS>(a, st); return true; }
+        if (xc <= 3) { launch_ksplit<M, 2, 3, WBITS, true>(a, st); return true; }
     }
     if constexpr (M * 4 * XE <= 16 && WBITS == 16) {
         if (xc <= 4) { launch_ksplit<M, 4, 4, WBITS>(a, st); return true; }
