@@ -15,16 +15,16 @@
 // HBM-bound: algorithmic bytes = 2 * step * kvh * hs * sizeof(T) per sequence.
 #include "device_utils.cuh"
 
+#include <cstdlib>
+
 namespace llmie {
 
-constexpr int kAttnWaves = 4;
-constexpr int kAttnG = 8;  // K (and V) 16-byte loads in flight per lane
-
-template <typename T, int HS> struct AttnGeom {
+// geometry of the split kernel: NWV waves per workgroup, GL K (and V) 16-byte loads in flight per lane
+template <typename T, int HS, int NWV = 4, int GL = 8> struct AttnGeom {
     static constexpr int N = Vec16<T>::n;            // elements per 16-byte load
     static constexpr int LPT = HS / N;               // lanes per token row
     static constexpr int TPW = 64 / LPT;             // token rows per wave instruction
-    static constexpr int CHUNK = kAttnWaves * kAttnG * TPW;  // tokens per workgroup
+    static constexpr int CHUNK = NWV * GL * TPW;     // tokens per workgroup
 };
 
 __host__ __device__ inline int attn_min_chunk() { return 32; }
@@ -62,16 +62,17 @@ __device__ __forceinline__ float merge_splits(const float *__restrict__ p, int n
     return o / (L + 1e-6f);
 }
 
-template <typename T, int HS, int REP>
-__global__ __launch_bounds__(256) void decode_attn_split_kernel(
+template <typename T, int HS, int REP, int kAttnWaves = 4, int kAttnG = 8>
+__global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
     const T *__restrict__ qkv, const T *__restrict__ qkv_bias, T *k_cache, T *v_cache,
     float *__restrict__ part, T *__restrict__ out, int head_num, int kv_head_num, int max_seq_len,
     int step_arg, const int32_t *__restrict__ step_dev, int max_splits,
     const float2 *__restrict__ rope /* [max_pos][HS/2] (cos,sin) or null */, int rotary_dim,
     int32_t *tickets /* [batch, kv_head_num] zero-initialised arrival counters, or null = separate merge kernel */) {
-    using G = AttnGeom<T, HS>;
+    using G = AttnGeom<T, HS, kAttnWaves, kAttnG>;
     using V = typename Vec16<T>::type;
     constexpr int N = G::N, LPT = G::LPT, TPW = G::TPW, CHUNK = G::CHUNK;
+    constexpr int NT = kAttnWaves * 64;
     static_assert(HS % N == 0 && LPT >= 1 && LPT <= 64 && (LPT & (LPT - 1)) == 0, "head size");
 
     const int step = step_dev ? *step_dev : step_arg;
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < REP * HS; i += 256) {
+    for (int i = threadIdx.x; i < REP * HS; i += NT) {
         const int r = i / HS, d = i - r * HS;
         float M = s_m[r][0];
 #pragma unroll
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
             }
             __syncthreads();
             const size_t stride = static_cast<size_t>(HS) + 2;
-            for (int i = threadIdx.x; i < REP * HS; i += 256) {
+            for (int i = threadIdx.x; i < REP * HS; i += NT) {
                 const int r = i / HS, d = i - r * HS;
                 const int h = g * REP + r;
                 const float *p = part + (static_cast<size_t>(b) * head_num + h) * max_splits * stride;
@@ -397,13 +398,22 @@ template <typename T, int HS, int REP>
 static void launch_split(const T *qkv, const T *bias, T *kc, T *vc, float *part, T *out, int batch,
                          int head_num, int kv_head_num, int max_seq_len, int step, const int32_t *step_dev,
                          int max_splits_ws, const float2 *rope, int rot_dim, int32_t *tickets, hipStream_t st) {
-    constexpr int CHUNK = AttnGeom<T, HS>::CHUNK;
+    static const int cfg = getenv("LLMIE_ATTN_CFG") ? atoi(getenv("LLMIE_ATTN_CFG")) : 0;
     const int bound = step_dev ? max_seq_len : step;
-    const int splits = (bound + CHUNK - 1) / CHUNK;
-    dim3 grid(splits, kv_head_num, batch);
-    decode_attn_split_kernel<T, HS, REP><<<grid, 256, 0, st>>>(qkv, bias, kc, vc, part, out, head_num,
-                                                               kv_head_num, max_seq_len, step, step_dev, max_splits_ws,
-                                                               rope, rot_dim, tickets);
+    int CHUNK, splits;
+#define LLMIE_ATTN_LAUNCH(NWV_, GL_)                                                                                   \
+    do {                                                                                                                \
+        CHUNK = AttnGeom<T, HS, NWV_, GL_>::CHUNK;                                                                      \
+        splits = (bound + CHUNK - 1) / CHUNK;                                                                           \
+        dim3 grid(splits, kv_head_num, batch);                                                                          \
+        decode_attn_split_kernel<T, HS, REP, NWV_, GL_><<<grid, NWV_ * 64, 0, st>>>(                                    \
+            qkv, bias, kc, vc, part, out, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, \
+            tickets);                                                                                                   \
+    } while (0)
+    if (cfg == 1) LLMIE_ATTN_LAUNCH(8, 8);
+    else if (cfg == 2) LLMIE_ATTN_LAUNCH(4, 4);
+    else LLMIE_ATTN_LAUNCH(4, 8);
+#undef LLMIE_ATTN_LAUNCH
     if (splits > 1 && !tickets) {
         dim3 cgrid(head_num, batch);
         decode_attn_combine_kernel<T><<<cgrid, HS < 64 ? 64 : (HS > 256 ? 256 : HS), 0, st>>>(part, out, head_num, HS, CHUNK,

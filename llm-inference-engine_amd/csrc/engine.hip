@@ -359,13 +359,21 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
         TIMED(LLMIE_OP_ATTN_NORM, llmie_rmsnorm(h, dec->resid, w.attn_norm_gamma, c.rms_eps, batch, H, dt, stream));
         // self_attention.cpp:79  qkv = h . Wqkv^T   (bias is applied inside the MHA kernel, as the reference)
         TIMED(LLMIE_OP_QKV_GEMM, engine_linear(dec, c.wfmt, h, w.qkv, dec->qkv, batch, H, QKV, false, nullptr, false, stream));
-        // :100 RoPE at position step-1
-        TIMED(LLMIE_OP_ROPE, llmie_rope_decode(dec->qkv, batch, c.head_num, c.kv_head_num, c.head_size, step, step_dev,
-                                               c.rotary_dim, c.rotary_base, dt, stream));
-        // :108 fused masked MHA with KV append
-        TIMED(LLMIE_OP_MHA, llmie_decoder_mha(dec->qkv, w.qkv.bias, k_cache, v_cache, dec->mha, l, batch, c.head_num,
-                                              c.kv_head_num, c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws,
-                                              dec->attn_ws_bytes, dt, stream));
+        if (hs_ok && rep_ok) {
+            // :100-:108 RoPE at position step-1 + fused masked MHA with KV append, one launch (+ merge)
+            TIMED(LLMIE_OP_MHA, decoder_mha_rope(dec->qkv, w.qkv.bias, k_cache, v_cache, dec->mha, l, batch, c.head_num,
+                                                 c.kv_head_num, c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws,
+                                                 dec->attn_ws_bytes, dec->rope_table, c.rotary_dim, nullptr, dt,
+                                                 as_stream(stream)));
+        } else {
+            // :100 RoPE at position step-1
+            TIMED(LLMIE_OP_ROPE, llmie_rope_decode(dec->qkv, batch, c.head_num, c.kv_head_num, c.head_size, step, step_dev,
+                                                   c.rotary_dim, c.rotary_base, dt, stream));
+            // :108 fused masked MHA with KV append
+            TIMED(LLMIE_OP_MHA, llmie_decoder_mha(dec->qkv, w.qkv.bias, k_cache, v_cache, dec->mha, l, batch, c.head_num,
+                                                  c.kv_head_num, c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws,
+                                                  dec->attn_ws_bytes, dt, stream));
+        }
         // :131 output projection (no bias here: the fused norm below adds o.bias, self_decoder.cpp:92-98)
         TIMED(LLMIE_OP_O_GEMM, engine_linear(dec, c.wfmt, dec->mha, w.o, h, batch, H, H, false, nullptr, false, stream));
         // self_decoder.cpp:92  h += resid; resid = h; h += o.bias; h = rmsnorm(h, ffn_gamma)
