@@ -54,6 +54,86 @@ public:
 };
 }  // namespace llmie_api
 
+// Lazily created fused engine (include/llmie.h section 3) shared by the two decoder classes: eligible when every
+// matrix of every layer is in HF layout ([N,K], is_transposed == true).
+template <typename T> class EngineHolder {
+    llmie_decoder *engine = nullptr;
+    void *ws = nullptr;
+    const void *key = nullptr;
+    int batch_cap = 0, max_seq = 0;
+    void *pf_ws = nullptr;
+    size_t pf_cap = 0;
+
+public:
+    ~EngineHolder() { destroy(); }
+    EngineHolder() = default;
+    EngineHolder(const EngineHolder &) = delete;
+    EngineHolder &operator=(const EngineHolder &) = delete;
+    static bool usable(std::vector<LlamaLayerWeight<T> *> *lw) {
+        for (auto *w : *lw)
+            if (!(w->self_attention_weight.qkv.is_transposed && w->self_attention_weight.output.is_transposed &&
+                  w->ffn_weight.gate_and_up.is_transposed && w->ffn_weight.down.is_transposed))
+                return false;
+        return true;
+    }
+    void destroy() {
+        if (engine) llmie_decoder_destroy(engine);
+        if (ws) (void)hipFree(ws);
+        if (pf_ws) (void)hipFree(pf_ws);
+        engine = nullptr;
+        ws = pf_ws = nullptr;
+        pf_cap = 0;
+    }
+    llmie_decoder *get(std::vector<LlamaLayerWeight<T> *> *lw, int num_layer, int head_num, int kv_head_num, int head_size,
+                       int inter_size, const LlamaAttentionStaticParams &sp, float eps, int batch, int max_seq_len) {
+        if (engine && key == lw->data() && batch <= batch_cap && max_seq_len == max_seq) return engine;
+        destroy();
+        llmie_decoder_config cfg{};
+        cfg.head_num = head_num;
+        cfg.kv_head_num = kv_head_num;
+        cfg.head_size = head_size;
+        cfg.inter_size = inter_size;
+        cfg.num_layers = num_layer;
+        cfg.vocab_size = 0;
+        cfg.max_seq_len = max_seq_len;
+        cfg.max_batch = batch;
+        cfg.rotary_dim = sp.rotary_embedding_dim;
+        cfg.rotary_base = sp.rotary_embedding_base;
+        cfg.rms_eps = eps;
+        cfg.dtype = llmie_api::dtype_of<T>();
+        cfg.wfmt = std::is_same<T, half>::value ? LLMIE_W_F16 : LLMIE_W_F32;
+        cfg.int4_group = 128;
+        std::vector<llmie_layer_weights> layers(num_layer);
+        for (int l = 0; l < num_layer; ++l) {
+            LlamaLayerWeight<T> *w = lw->at(l);
+            layers[l].attn_norm_gamma = w->attention_norm_weight.gamma;
+            layers[l].ffn_norm_gamma = w->ffn_norm_weight.gamma;
+            layers[l].qkv = {w->self_attention_weight.qkv.data, nullptr, w->self_attention_weight.qkv.bias};
+            layers[l].o = {w->self_attention_weight.output.data, nullptr, w->self_attention_weight.output.bias};
+            layers[l].gate_up = {w->ffn_weight.gate_and_up.data, nullptr, nullptr};
+            layers[l].down = {w->ffn_weight.down.data, nullptr, nullptr};
+        }
+        const size_t bytes = llmie_decoder_workspace_bytes(&cfg);
+        LLM_CHECK_WITH_INFO(bytes > 0, "invalid decoder configuration");
+        CHECK(hipMalloc(&ws, bytes));
+        engine = llmie_decoder_create(&cfg, layers.data(), ws, bytes);
+        LLM_CHECK_WITH_INFO(engine != nullptr, std::string(llmie_last_error()));
+        key = lw->data();
+        batch_cap = batch;
+        max_seq = max_seq_len;
+        return engine;
+    }
+    void *prefill_workspace(const llmie_decoder_config *cfg, int tokens, int batch, size_t *bytes) {
+        *bytes = llmie_decoder_prefill_workspace_bytes(cfg, tokens, batch);
+        if (*bytes > pf_cap) {
+            if (pf_ws) CHECK(hipFree(pf_ws));
+            CHECK(hipMalloc(&pf_ws, *bytes));
+            pf_cap = *bytes;
+        }
+        return pf_ws;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 template <typename T> class LlamaSelfAttentionLayer {
 private:
@@ -181,62 +261,7 @@ private:
     LlamaSelfAttentionLayer<T> *self_attention;
     LlamaFFNLayer<T> *ffn;
     DataType data_type;
-    // fused engine (include/llmie.h section 3), created lazily for HF-layout ([N,K]) weights
-    llmie_decoder *engine = nullptr;
-    void *engine_ws = nullptr;
-    const void *engine_key = nullptr;
-    int engine_batch = 0, engine_max_seq = 0;
-
-    bool engine_usable(std::vector<LlamaLayerWeight<T> *> *lw) const {
-        for (auto *w : *lw)
-            if (!(w->self_attention_weight.qkv.is_transposed && w->self_attention_weight.output.is_transposed &&
-                  w->ffn_weight.gate_and_up.is_transposed && w->ffn_weight.down.is_transposed))
-                return false;
-        return true;
-    }
-    void destroy_engine() {
-        if (engine) llmie_decoder_destroy(engine);
-        if (engine_ws) (void)hipFree(engine_ws);
-        engine = nullptr;
-        engine_ws = nullptr;
-    }
-    void ensure_engine(std::vector<LlamaLayerWeight<T> *> *lw, int batch, int max_seq_len) {
-        if (engine && engine_key == lw->data() && batch <= engine_batch && max_seq_len == engine_max_seq) return;
-        destroy_engine();
-        llmie_decoder_config cfg{};
-        cfg.head_num = head_num;
-        cfg.kv_head_num = kv_head_num;
-        cfg.head_size = head_size;
-        cfg.inter_size = intermediate_size;
-        cfg.num_layers = num_layer;
-        cfg.vocab_size = 0;
-        cfg.max_seq_len = max_seq_len;
-        cfg.max_batch = batch;
-        cfg.rotary_dim = static_params.rotary_embedding_dim;
-        cfg.rotary_base = static_params.rotary_embedding_base;
-        cfg.rms_eps = rmsnorm_eps;
-        cfg.dtype = llmie_api::dtype_of<T>();
-        cfg.wfmt = std::is_same<T, half>::value ? LLMIE_W_F16 : LLMIE_W_F32;
-        cfg.int4_group = 128;
-        std::vector<llmie_layer_weights> layers(num_layer);
-        for (int l = 0; l < num_layer; ++l) {
-            LlamaLayerWeight<T> *w = lw->at(l);
-            layers[l].attn_norm_gamma = w->attention_norm_weight.gamma;
-            layers[l].ffn_norm_gamma = w->ffn_norm_weight.gamma;
-            layers[l].qkv = {w->self_attention_weight.qkv.data, nullptr, w->self_attention_weight.qkv.bias};
-            layers[l].o = {w->self_attention_weight.output.data, nullptr, w->self_attention_weight.output.bias};
-            layers[l].gate_up = {w->ffn_weight.gate_and_up.data, nullptr, nullptr};
-            layers[l].down = {w->ffn_weight.down.data, nullptr, nullptr};
-        }
-        const size_t bytes = llmie_decoder_workspace_bytes(&cfg);
-        LLM_CHECK_WITH_INFO(bytes > 0, "invalid decoder configuration");
-        CHECK(hipMalloc(&engine_ws, bytes));
-        engine = llmie_decoder_create(&cfg, layers.data(), engine_ws, bytes);
-        LLM_CHECK_WITH_INFO(engine != nullptr, std::string(llmie_last_error()));
-        engine_key = lw->data();
-        engine_batch = batch;
-        engine_max_seq = max_seq_len;
-    }
+    EngineHolder<T> engine_holder;
 
 public:
     LlamaSelfDecoder(const int &head_num, const int &kv_head_num, const int &head_size, const int &intermediate_size,
@@ -251,7 +276,6 @@ public:
         ffn = new LlamaFFNLayer<T>(head_num, head_size, intermediate_size, stream, cublas_wrapper, allocator);
     }
     ~LlamaSelfDecoder() {
-        destroy_engine();
         delete self_attention;
         delete ffn;
     }
@@ -284,8 +308,10 @@ public:
         LLM_CHECK_WITH_INFO(static_cast<int>(layer_weights->size()) >= num_layer, "not enough layer weights");
         const int batch = dynamic_params->batch_size;
 
-        if (use_fused_engine && engine_usable(layer_weights)) {
-            ensure_engine(layer_weights, batch, all_k_cache->shape[3]);
+        if (use_fused_engine && EngineHolder<T>::usable(layer_weights)) {
+            llmie_decoder *engine = engine_holder.get(layer_weights, num_layer, head_num, kv_head_num, head_size,
+                                                      intermediate_size, static_params, rmsnorm_eps, batch,
+                                                      all_k_cache->shape[3]);
             LLMIE_CALL(llmie_decoder_forward(engine, decoder_input->wrap<T>()->data, decoder_output->wrap<T>()->data,
                                              all_k_cache->wrap<T>()->data, all_v_cache->wrap<T>()->data, batch,
                                              step->wrap<int>()->getVal(), nullptr, llmie_api::st()));
@@ -428,8 +454,13 @@ private:
     LlamaContextAttentionLayer<T> *context_attention = nullptr;
     LlamaFFNLayer<T> *ffn = nullptr;
     DataType data_type;
+    EngineHolder<T> engine_holder;
 
 public:
+    // set false to force the reference's kernel sequence (padded q/k/v, batched GEMMs, softmax) even when the
+    // flash-attention engine path (fp16, head_size 128, HF-layout weights) is eligible
+    bool use_fused_engine = true;
+
     LlamaContextDecoder(const int &head_num, const int &kv_head_num, const int &head_size, const int &intermediate_size,
                         const int &num_layer, LlamaAttentionStaticParams *const &attention_static_params,
                         const float &rmsnorm_eps, const hipStream_t &stream, CublasWrapper *const &cublas_wrapper,
@@ -462,6 +493,31 @@ public:
     // context_decoder.cpp:58-199
     void forward(TensorMap *input_tensors, std::vector<LlamaLayerWeight<T> *> *layer_weights, TensorMap *output_tensors,
                  LlamaAttentionDynamicParams *attention_dynamic_params) {
+        if (use_fused_engine && std::is_same<T, half>::value && head_size == 128 && EngineHolder<T>::usable(layer_weights)) {
+            // engine prefill: packed tokens, RoPE + KV append + flash attention (include/llmie.h llmie_decoder_prefill)
+            Tensor *seq_lens = input_tensors->at("input_length");
+            Tensor *history_length = input_tensors->at("history_length");
+            Tensor *decoder_input = input_tensors->at("decoder_input");
+            Tensor *decoder_output = output_tensors->at("decoder_output");
+            Tensor *all_k_cache = output_tensors->at("all_k_cache");
+            Tensor *all_v_cache = output_tensors->at("all_v_cache");
+            const int batch = attention_dynamic_params->batch_size, tokens = attention_dynamic_params->num_tokens;
+            LlamaAttentionStaticParams *sp = context_attention->getAttentionStaticParams();
+            llmie_decoder *engine = engine_holder.get(layer_weights, num_layer, head_num, kv_head_num, head_size,
+                                                      intermediate_size, *sp, rmsnorm_eps, batch, all_k_cache->shape[3]);
+            llmie_decoder_config cfg{};
+            cfg.head_num = head_num; cfg.kv_head_num = kv_head_num; cfg.head_size = head_size;
+            cfg.inter_size = intermediate_size; cfg.num_layers = num_layer; cfg.max_seq_len = all_k_cache->shape[3];
+            cfg.max_batch = batch; cfg.rotary_dim = sp->rotary_embedding_dim; cfg.rotary_base = sp->rotary_embedding_base;
+            cfg.rms_eps = rmsnorm_eps; cfg.dtype = LLMIE_F16; cfg.wfmt = LLMIE_W_F16; cfg.int4_group = 128;
+            size_t bytes = 0;
+            void *pws = engine_holder.prefill_workspace(&cfg, tokens, batch, &bytes);
+            LLMIE_CALL(llmie_decoder_prefill(engine, decoder_input->wrap<T>()->data, decoder_output->wrap<T>()->data,
+                                             all_k_cache->wrap<T>()->data, all_v_cache->wrap<T>()->data,
+                                             seq_lens->wrap<int>()->data, history_length->wrap<int>()->data, batch, tokens,
+                                             attention_dynamic_params->max_q_len, pws, bytes, llmie_api::st()));
+            return;
+        }
         allocateMemory(attention_dynamic_params);
         Tensor *seq_lens = input_tensors->at("input_length");
         launchCalPaddingOffset(padding_offset, cum_seqlens, seq_lens->wrap<int>());

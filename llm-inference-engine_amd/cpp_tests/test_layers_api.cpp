@@ -187,6 +187,19 @@ template <typename T> static void run(bool fp16) {
         dyn.max_k_len = mk;
         LlamaContextDecoder<T> cdec(nh, kvh, hs, I, L, &sp, eps, stream, &gemm, &alloc);
         cdec.forward(&inputs, &m.ptrs, &outputs, &dyn);
+        {   // the reference's kernel sequence (padded q/k/v, batched GEMMs, softmax) gives the same hidden state
+            DeviceArray<T> din2(cast_vec<T>(x)), dout2(x.size()), dk2(cast_vec<T>(kc)), dv2(cast_vec<T>(vc));
+            TensorWrapper<T> tin2(Device::GPU, ty, {Tn, H}, din2.d), tout2(Device::GPU, ty, {Tn, H}, dout2.d);
+            TensorWrapper<T> tk2(Device::GPU, ty, {L, bs, kvh, max_seq, hs}, dk2.d), tv2(Device::GPU, ty, {L, bs, kvh, max_seq, hs}, dv2.d);
+            TensorMap inputs2{{"decoder_input", &tin2}, {"history_length", &thist}, {"input_length", &tlen},
+                              {"context_length", &tctx}, {"layer_id", &tlayer}};
+            TensorMap outputs2{{"decoder_output", &tout2}, {"all_k_cache", &tk2}, {"all_v_cache", &tv2}};
+            LlamaContextDecoder<T> cdec2(nh, kvh, hs, I, L, &sp, eps, stream, &gemm, &alloc);
+            cdec2.use_fused_engine = false;
+            cdec2.forward(&inputs2, &m.ptrs, &outputs2, &dyn);
+            check_close("LlamaContextDecoder engine path == per-kernel path", to_float(dout.download()),
+                        to_float(dout2.download()), rt, at);
+        }
         oracle_context_decoder(m, x, kc, vc, lens, hist, max_seq, rot, base, eps);
         check_close("LlamaContextDecoder", to_float(dout.download()), x, rt, at);
         // layer >= 1 K rows come out of a full fp16 layer: same tolerance as the hidden state
