@@ -13,7 +13,7 @@
 // (m, l, o[hs]) partial.  A second tiny kernel merges the partials.  bs*kvh*splits workgroups
 // fill the 256 CUs even at batch 1 (7B, S=2048: 32*16 = 512 workgroups).
 // HBM-bound: algorithmic bytes = 2 * step * kvh * hs * sizeof(T) per sequence.
-#include "device_utils.cuh"
+#include "llmie_internal.h"
 
 #include <cstdlib>
 
@@ -28,6 +28,14 @@ template <typename T, int HS, int NWV = 4, int GL = 8> struct AttnGeom {
 };
 
 __host__ __device__ inline int attn_min_chunk() { return 32; }
+
+// q/k/v source when the QKV projection's split-K finalize is fused into the attention: fp32 slabs [KS][batch][qkv_dim]
+struct QkvSlabs {
+    const float *slab;
+    int KS;
+    size_t stride;          // floats between slabs (= batch * qkv_dim)
+    const half_t *wscale;   // per-output-channel weight scale (int8) or null
+};
 
 // Merge of the per-split (m, l, o[d]) partials of one (batch, head) for output dim d: 16 splits per round,
 // every load of a round issued before the first use.  Shared by the stand-alone merge kernel and by the
@@ -68,7 +76,8 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
     float *__restrict__ part, T *__restrict__ out, int head_num, int kv_head_num, int max_seq_len,
     int step_arg, const int32_t *__restrict__ step_dev, int max_splits,
     const float2 *__restrict__ rope /* [max_pos][HS/2] (cos,sin) or null */, int rotary_dim,
-    int32_t *tickets /* [batch, kv_head_num] zero-initialised arrival counters, or null = separate merge kernel */) {
+    int32_t *tickets /* [batch, kv_head_num] zero-initialised arrival counters, or null = separate merge kernel */,
+    const QkvSlabs qs /* qs.slab != null: q/k/v come from the split-K partial slabs of the QKV projection (qkv unused) */) {
     using G = AttnGeom<T, HS, kAttnWaves, kAttnG>;
     using V = typename Vec16<T>::type;
     constexpr int N = G::N, LPT = G::LPT, TPW = G::TPW, CHUNK = G::CHUNK;
@@ -96,9 +105,53 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
     const int t_new = step - 1;
     // small L2-resident operands first (q rows, RoPE row), then the K/V stream; q is processed after the K/V
     // loads have been issued, so its latency hides under theirs (vmcnt retires in order: q is older)
+    // Slab mode (q/k/v still in the QKV projection's split-K slabs): the rows this workgroup needs -- REP q heads, plus
+    // the new k and v rows when its chunk holds this step's token -- are reduced ONCE per workgroup into LDS by the
+    // first threads (one float4 column each, all slab loads in flight together, summed in the finalize kernel's
+    // order, scaled and rounded like it) instead of by every lane (16 lanes x 4 waves hold the same q slice).
     V qraw[REP];
+    constexpr int ITEMS_PER_HEAD = HS / 4;
+    constexpr int LROUNDS = ((REP + 2) * ITEMS_PER_HEAD + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) T qkvlds[(REP + 2) * HS];
+    const bool wg_has_new = t_new >= t0 && t_new < t0 + CHUNK;  // workgroup-uniform
+    floatx4 spart[LROUNDS][4];
+    half4_t sscale[LROUNDS];
+    size_t scol[LROUNDS];
+    bool sact[LROUNDS];
+    if (qs.slab) {
 #pragma unroll
-    for (int r = 0; r < REP; ++r) qraw[r] = reinterpret_cast<const V *>(row + static_cast<size_t>(g * REP + r) * HS)[dl];
+        for (int lr = 0; lr < LROUNDS; ++lr) {
+            const int item = lr * NT + threadIdx.x;
+            const int hsel = item / ITEMS_PER_HEAD, d4 = item - hsel * ITEMS_PER_HEAD;
+            sact[lr] = hsel < REP || (wg_has_new && hsel < REP + 2);
+            const int hh = hsel < REP ? g * REP + hsel : (hsel == REP ? head_num + g : head_num + kv_head_num + g);
+            scol[lr] = static_cast<size_t>(hh) * HS + d4 * 4;
+            if (sact[lr]) {
+                const float *p = qs.slab + static_cast<size_t>(b) * qkv_heads * HS + scol[lr];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    spart[lr][kk] = *reinterpret_cast<const floatx4 *>(p + static_cast<size_t>(min(kk, qs.KS - 1)) * qs.stride);
+                if (qs.wscale) sscale[lr] = *reinterpret_cast<const half4_t *>(qs.wscale + scol[lr]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < REP; ++r) qraw[r] = reinterpret_cast<const V *>(row + static_cast<size_t>(g * REP + r) * HS)[dl];
+    }
+    // this step's k/v rows and the bias slices: loaded by every workgroup, unconditionally (a load under a divergent
+    // or data-dependent branch makes the compiler drain vmcnt at the join -- measured: the K/V stream below used to
+    // stall after its second load).  Without a bias / outside slab mode the address is a dummy valid one (the head's
+    // first cache row) and the value is dropped by a select.
+    const int hk = head_num + g, hv = head_num + kv_head_num + g;
+    const T *dummy = kc;
+    V knraw = reinterpret_cast<const V *>(qs.slab ? dummy : row + static_cast<size_t>(hk) * HS)[dl];
+    V vnraw = reinterpret_cast<const V *>(qs.slab ? dummy : row + static_cast<size_t>(hv) * HS)[dl];
+    V qbias[REP], kbias, vbias;
+#pragma unroll
+    for (int r = 0; r < REP; ++r)
+        qbias[r] = reinterpret_cast<const V *>(qkv_bias ? qkv_bias + static_cast<size_t>(g * REP + r) * HS : dummy)[dl];
+    kbias = reinterpret_cast<const V *>(qkv_bias ? qkv_bias + static_cast<size_t>(hk) * HS : dummy)[dl];
+    vbias = reinterpret_cast<const V *>(qkv_bias ? qkv_bias + static_cast<size_t>(hv) * HS : dummy)[dl];
     float2 csraw[N];
     if (rope) {
         const float2 *cs = rope + static_cast<size_t>(t_new) * (HS / 2) + (dl % (LPT / 2)) * N;
@@ -112,12 +165,31 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
     for (int i = 0; i < kAttnG; ++i) {
         const int t = t0 + (wave * kAttnG + i) * TPW + sub;
         tok[i] = t;
-        if (t < t_end && t != t_new) kv[i] = load_nt(reinterpret_cast<const V *>(kc + static_cast<size_t>(t) * HS) + dl);
+        // rows past the chunk end re-read its last row (masked below); the slot of this step's token is read as it is
+        // (stale, replaced below): every load is unconditional so all 2*G of them are in flight together
+        kv[i] = load_nt(reinterpret_cast<const V *>(kc + static_cast<size_t>(min(t, t_end - 1)) * HS) + dl);
     }
 #pragma unroll
-    for (int i = 0; i < kAttnG; ++i) {
-        const int t = tok[i];
-        if (t < t_end && t != t_new) vv[i] = load_nt(reinterpret_cast<const V *>(vc + static_cast<size_t>(t) * HS) + dl);
+    for (int i = 0; i < kAttnG; ++i)
+        vv[i] = load_nt(reinterpret_cast<const V *>(vc + static_cast<size_t>(min(tok[i], t_end - 1)) * HS) + dl);
+    if (qs.slab) {
+#pragma unroll
+        for (int lr = 0; lr < LROUNDS; ++lr) {
+            if (sact[lr]) {
+                const float *p = qs.slab + static_cast<size_t>(b) * qkv_heads * HS + scol[lr];
+                floatx4 f = spart[lr][0];
+#pragma unroll
+                for (int kk = 1; kk < 4; ++kk)
+                    if (kk < qs.KS) f += spart[lr][kk];
+                for (int k = 4; k < qs.KS; ++k) f += *reinterpret_cast<const floatx4 *>(p + static_cast<size_t>(k) * qs.stride);
+                const int item = lr * NT + threadIdx.x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qkvlds[item * 4 + e] = from_f32<T>(qs.wscale ? f[e] * to_f32(sscale[lr][e]) : f[e]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < REP; ++r) qraw[r] = *reinterpret_cast<const V *>(&qkvlds[r * HS + dl * N]);
     }
     // RoPE (fused form of launchRope, rope.cu:4-43): rotate-half pairs (d, d+HS/2) live LPT/2 lanes apart
     const bool rope_first = dl < LPT / 2;
@@ -141,7 +213,6 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
     float qf[REP][N];
 #pragma unroll
     for (int r = 0; r < REP; ++r) {
-        const int h = g * REP + r;
         const V qv = qraw[r];
         float f[N];
 #pragma unroll
@@ -153,36 +224,44 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
         }
 #pragma unroll
         for (int e = 0; e < N; ++e) {
-            if (qkv_bias) f[e] += to_f32(qkv_bias[static_cast<size_t>(h) * HS + dl * N + e]);
+            f[e] += qkv_bias ? to_f32(qbias[r][e]) : 0.f;
             qf[r][e] = f[e] * scale;
         }
     }
 
-    // the token of this step comes from the qkv buffer (+bias) and is appended to the cache
+    // the token of this step comes from the qkv buffer / slabs (RoPE, then +bias, as the reference's rope.cu then
+    // decoder_self_attention.cu:111-118) and is appended to the cache; computed by every lane, kept by the token's lanes
+    {
+        V kn = knraw, vn = vnraw;
+        if (qs.slab) {
+            kn = *reinterpret_cast<const V *>(&qkvlds[REP * HS + dl * N]);
+            vn = *reinterpret_cast<const V *>(&qkvlds[(REP + 1) * HS + dl * N]);
+        }
+        if (rope) {
+            float f[N];
 #pragma unroll
-    for (int i = 0; i < kAttnG; ++i) {
-        if (tok[i] == t_new) {
-            const int hk = head_num + g, hv = head_num + kv_head_num + g;
-            V kn = reinterpret_cast<const V *>(row + static_cast<size_t>(hk) * HS)[dl];
-            V vn = reinterpret_cast<const V *>(row + static_cast<size_t>(hv) * HS)[dl];
-            if (rope) {
-                // every lane of the wave takes part in the shuffles: only lanes of this token keep the result
-                float f[N];
+            for (int e = 0; e < N; ++e) f[e] = to_f32(kn[e]);
+            rotate(f);
 #pragma unroll
-                for (int e = 0; e < N; ++e) f[e] = to_f32(kn[e]);
-                rotate(f);
+            for (int e = 0; e < N; ++e) kn[e] = from_f32<T>(f[e]);
+        }
 #pragma unroll
-                for (int e = 0; e < N; ++e) kn[e] = from_f32<T>(f[e]);
+        for (int e = 0; e < N; ++e) {
+            kn[e] = qkv_bias ? from_f32<T>(to_f32(kn[e]) + to_f32(kbias[e])) : kn[e];
+            vn[e] = qkv_bias ? from_f32<T>(to_f32(vn[e]) + to_f32(vbias[e])) : vn[e];
+        }
+        bool mine = false;
+#pragma unroll
+        for (int i = 0; i < kAttnG; ++i) {
+            const bool is_new = tok[i] == t_new;
+            mine |= is_new;
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                kv[i][e] = is_new ? kn[e] : kv[i][e];
+                vv[i][e] = is_new ? vn[e] : vv[i][e];
             }
-            if (qkv_bias) {
-#pragma unroll
-                for (int e = 0; e < N; ++e) {
-                    kn[e] = from_f32<T>(to_f32(kn[e]) + to_f32(qkv_bias[static_cast<size_t>(hk) * HS + dl * N + e]));
-                    vn[e] = from_f32<T>(to_f32(vn[e]) + to_f32(qkv_bias[static_cast<size_t>(hv) * HS + dl * N + e]));
-                }
-            }
-            kv[i] = kn;
-            vv[i] = vn;
+        }
+        if (mine) {
             reinterpret_cast<V *>(kc + static_cast<size_t>(t_new) * HS)[dl] = kn;
             reinterpret_cast<V *>(vc + static_cast<size_t>(t_new) * HS)[dl] = vn;
         }
@@ -397,7 +476,8 @@ __global__ __launch_bounds__(256) void decode_attn_generic_kernel(
 template <typename T, int HS, int REP>
 static void launch_split(const T *qkv, const T *bias, T *kc, T *vc, float *part, T *out, int batch,
                          int head_num, int kv_head_num, int max_seq_len, int step, const int32_t *step_dev,
-                         int max_splits_ws, const float2 *rope, int rot_dim, int32_t *tickets, hipStream_t st) {
+                         int max_splits_ws, const float2 *rope, int rot_dim, int32_t *tickets, const QkvSlabs &qs,
+                         hipStream_t st) {
     static const int cfg = getenv("LLMIE_ATTN_CFG") ? atoi(getenv("LLMIE_ATTN_CFG")) : 0;
     const int bound = step_dev ? max_seq_len : step;
     int CHUNK, splits;
@@ -408,7 +488,7 @@ static void launch_split(const T *qkv, const T *bias, T *kc, T *vc, float *part,
         dim3 grid(splits, kv_head_num, batch);                                                                          \
         decode_attn_split_kernel<T, HS, REP, NWV_, GL_><<<grid, NWV_ * 64, 0, st>>>(                                    \
             qkv, bias, kc, vc, part, out, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, \
-            tickets);                                                                                                   \
+            tickets, qs);                                                                                               \
     } while (0)
     if (cfg == 1) LLMIE_ATTN_LAUNCH(8, 8);
     else if (cfg == 2) LLMIE_ATTN_LAUNCH(4, 4);
@@ -424,12 +504,13 @@ static void launch_split(const T *qkv, const T *bias, T *kc, T *vc, float *part,
 template <typename T, int HS>
 static bool dispatch_rep(int rep, const T *qkv, const T *bias, T *kc, T *vc, float *part, T *out, int batch,
                          int head_num, int kv_head_num, int max_seq_len, int step, const int32_t *step_dev,
-                         int max_splits_ws, const float2 *rope, int rot_dim, int32_t *tickets, hipStream_t st) {
+                         int max_splits_ws, const float2 *rope, int rot_dim, int32_t *tickets, const QkvSlabs &qs,
+                         hipStream_t st) {
     switch (rep) {
-        case 1: launch_split<T, HS, 1>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, st); return true;
-        case 2: launch_split<T, HS, 2>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, st); return true;
-        case 4: launch_split<T, HS, 4>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, st); return true;
-        case 8: launch_split<T, HS, 8>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, st); return true;
+        case 1: launch_split<T, HS, 1>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, st); return true;
+        case 2: launch_split<T, HS, 2>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, st); return true;
+        case 4: launch_split<T, HS, 4>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, st); return true;
+        case 8: launch_split<T, HS, 8>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, st); return true;
         default: return false;
     }
 }
@@ -438,7 +519,7 @@ template <typename T>
 static int decoder_mha_impl(const T *qkv, const T *bias, T *k_cache, T *v_cache, T *out, int layer, int batch,
                             int head_num, int kv_head_num, int head_size, int max_seq_len, int step,
                             const int32_t *step_dev, void *workspace, size_t workspace_bytes, const float2 *rope,
-                            int rot_dim, int32_t *tickets, hipStream_t st) {
+                            int rot_dim, int32_t *tickets, const QkvSlabs &qs, hipStream_t st) {
     const size_t layer_off = static_cast<size_t>(layer) * batch * kv_head_num * max_seq_len * head_size;
     T *kc = k_cache + layer_off, *vc = v_cache + layer_off;
     const int rep = head_num / kv_head_num;
@@ -451,18 +532,22 @@ static int decoder_mha_impl(const T *qkv, const T *bias, T *k_cache, T *v_cache,
         float *part = static_cast<float *>(workspace);
         auto ws_ok = [&]() { return workspace && workspace_bytes >= need; };
         if (head_size == 128 && ws_ok())
-            done = dispatch_rep<T, 128>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, st);
+            done = dispatch_rep<T, 128>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, st);
         else if (head_size == 64 && ws_ok())
-            done = dispatch_rep<T, 64>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, st);
+            done = dispatch_rep<T, 64>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, st);
         else if (head_size == 32 && ws_ok())
-            done = dispatch_rep<T, 32>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, st);
+            done = dispatch_rep<T, 32>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, st);
         else if (head_size == 256 && ws_ok())
-            done = dispatch_rep<T, 256>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, st);
+            done = dispatch_rep<T, 256>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, st);
         if (!done && (head_size == 128 || head_size == 64 || head_size == 32 || head_size == 256) && !ws_ok() &&
             (rep == 1 || rep == 2 || rep == 4 || rep == 8)) {
             set_error("decoder_mha: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
             return LLMIE_ERR_WORKSPACE;
         }
+    }
+    if (!done && qs.slab) {
+        set_error("decoder_mha: q/k/v from split-K slabs needs head_size in {32,64,128,256} and head_num/kv_head_num in {1,2,4,8}");
+        return LLMIE_ERR_UNSUPPORTED;
     }
     if (!done && rope) {
         set_error("decoder_mha: fused RoPE needs head_size in {32,64,128,256} and head_num/kv_head_num in {1,2,4,8}");
@@ -486,14 +571,21 @@ static int decoder_mha_impl(const T *qkv, const T *bias, T *k_cache, T *v_cache,
 int decoder_mha_rope(const void *qkv, const void *qkv_bias, void *k_cache, void *v_cache, void *out, int layer, int batch,
                      int head_num, int kv_head_num, int head_size, int max_seq_len, int step, const int32_t *step_dev,
                      void *workspace, size_t workspace_bytes, const float2 *rope, int rot_dim, int32_t *tickets,
-                     llmie_dtype dtype, hipStream_t st) {
+                     llmie_dtype dtype, hipStream_t st, const SplitKSlabs *qkv_slabs, const half_t *qkv_wscale) {
+    QkvSlabs qs{nullptr, 0, 0, nullptr};
+    if (qkv_slabs && (reinterpret_cast<uintptr_t>(qkv_wscale) % 8 || reinterpret_cast<uintptr_t>(qkv_slabs->slab) % 16 ||
+                      (static_cast<size_t>(qkv_slabs->M) * qkv_slabs->N) % 4)) {
+        set_error("decoder_mha: q/k/v from split-K slabs needs 16-byte aligned slabs and an 8-byte aligned scale vector");
+        return LLMIE_ERR_UNSUPPORTED;
+    }
+    if (qkv_slabs) qs = QkvSlabs{qkv_slabs->slab, qkv_slabs->KS, static_cast<size_t>(qkv_slabs->M) * qkv_slabs->N, qkv_wscale};
     if (dtype == LLMIE_F32)
         return decoder_mha_impl<float>((const float *)qkv, (const float *)qkv_bias, (float *)k_cache, (float *)v_cache,
                                        (float *)out, layer, batch, head_num, kv_head_num, head_size, max_seq_len, step,
-                                       step_dev, workspace, workspace_bytes, rope, rot_dim, tickets, st);
+                                       step_dev, workspace, workspace_bytes, rope, rot_dim, tickets, qs, st);
     return decoder_mha_impl<half_t>((const half_t *)qkv, (const half_t *)qkv_bias, (half_t *)k_cache, (half_t *)v_cache,
                                     (half_t *)out, layer, batch, head_num, kv_head_num, head_size, max_seq_len, step,
-                                    step_dev, workspace, workspace_bytes, rope, rot_dim, tickets, st);
+                                    step_dev, workspace, workspace_bytes, rope, rot_dim, tickets, qs, st);
 }
 
 }  // namespace llmie
@@ -519,11 +611,11 @@ extern "C" int llmie_decoder_mha(const void *qkv, const void *qkv_bias, void *k_
     if (dtype == LLMIE_F32)
         return decoder_mha_impl<float>((const float *)qkv, (const float *)qkv_bias, (float *)k_cache, (float *)v_cache,
                                        (float *)out, layer, batch, head_num, kv_head_num, head_size, max_seq_len, step,
-                                       step_dev, workspace, workspace_bytes, nullptr, 0, nullptr, as_stream(stream));
+                                       step_dev, workspace, workspace_bytes, nullptr, 0, nullptr, QkvSlabs{nullptr, 0, 0, nullptr}, as_stream(stream));
     if (dtype == LLMIE_F16)
         return decoder_mha_impl<half_t>((const half_t *)qkv, (const half_t *)qkv_bias, (half_t *)k_cache,
                                         (half_t *)v_cache, (half_t *)out, layer, batch, head_num, kv_head_num, head_size,
-                                        max_seq_len, step, step_dev, workspace, workspace_bytes, nullptr, 0, nullptr, as_stream(stream));
+                                        max_seq_len, step, step_dev, workspace, workspace_bytes, nullptr, 0, nullptr, QkvSlabs{nullptr, 0, 0, nullptr}, as_stream(stream));
     LLMIE_UNSUPPORTED("decoder_mha: dtype %d", (int)dtype);
 }
 

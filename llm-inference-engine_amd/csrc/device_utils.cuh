@@ -6,6 +6,8 @@
 namespace llmie {
 
 using half_t = _Float16;
+typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef half_t half2_t __attribute__((ext_vector_type(2)));
 typedef half_t half4_t __attribute__((ext_vector_type(4)));
 typedef half_t half8_t __attribute__((ext_vector_type(8)));

@@ -353,6 +353,45 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
         return LLMIE_OK;
     }
 
+    // ---- fused batch decode path (8 < batch <= 128, fp16 or int8 weights): 8 launches per layer (+ the attention merge
+    // when the context spans several chunks) instead of 11-12.  Every projection is a split-K MFMA launch that leaves
+    // fp32 partial slabs; the consumer of each slab does the reduction:
+    //   qkv slabs            -> read directly by the attention launch (q rows, new k/v rows; + scale, bias, RoPE, append)
+    //   o / down slabs       -> splitk_rownorm: reduction + residual stream update + the NEXT RMSNorm in one launch
+    //   gate_up slabs        -> finalize with the SwiGLU epilogue
+    // (each small dependent launch costs ~4.5 us on MI355X, a third of a batch-32 int8 layer before this fusion)
+    static const int batch_fused_off = getenv("LLMIE_NO_FUSED_BATCH") ? 1 : 0;
+    if (!batch_fused_off && c.dtype == LLMIE_F16 && (wbits == 16 || wbits == 8) && hs_ok && rep_ok && batch <= 128 &&
+        H % 256 == 0 && I % 256 == 0 && H >= 512 && I >= 512 && splitk_rownorm_eligible(H)) {
+        hipStream_t st = as_stream(stream);
+        half_t *hh = static_cast<half_t *>(h), *resid = reinterpret_cast<half_t *>(dec->resid);
+        auto scale_of = [&](const llmie_matrix &m) { return wbits == 8 ? static_cast<const half_t *>(m.scale) : nullptr; };
+        // self_decoder.cpp:77 (first layer only: later ones get it from the previous layer's down-projection epilogue)
+        TIMED(LLMIE_OP_ATTN_NORM, llmie_rmsnorm(h, dec->resid, dec->layers[0].attn_norm_gamma, c.rms_eps, batch, H, dt, stream));
+        for (int l = 0; l < c.num_layers; ++l) {
+            const llmie_layer_weights &w = dec->layers[l];
+            SplitKSlabs sk;
+            TIMED(LLMIE_OP_QKV_GEMM, linear_splitk_partial(wbits, hh, w.qkv.data, batch, H, QKV, st, &sk));
+            TIMED(LLMIE_OP_MHA, decoder_mha_rope(nullptr, w.qkv.bias, k_cache, v_cache, dec->mha, l, batch, c.head_num,
+                                                 c.kv_head_num, c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws,
+                                                 dec->attn_ws_bytes, dec->rope_table, c.rotary_dim, nullptr, dt, st, &sk,
+                                                 scale_of(w.qkv)));
+            TIMED(LLMIE_OP_O_GEMM, linear_splitk_partial(wbits, reinterpret_cast<const half_t *>(dec->mha), w.o.data, batch, H, H, st, &sk));
+            // self_decoder.cpp:92  h += resid; resid = h; h += o.bias; h = rmsnorm(h, ffn_gamma)
+            TIMED(LLMIE_OP_FFN_NORM, splitk_rownorm(sk, scale_of(w.o), static_cast<const half_t *>(w.o.bias), resid,
+                                                    static_cast<const half_t *>(w.ffn_norm_gamma), c.rms_eps, hh, st));
+            TIMED(LLMIE_OP_GATE_UP_SWIGLU, linear_splitk(wbits, hh, w.gate_up.data, scale_of(w.gate_up),
+                                                         reinterpret_cast<half_t *>(dec->act), batch, H, 2 * I, EPI_SWIGLU_, nullptr,
+                                                         nullptr, st));
+            TIMED(LLMIE_OP_DOWN_GEMM, linear_splitk_partial(wbits, reinterpret_cast<const half_t *>(dec->act), w.down.data, batch, I, H, st, &sk));
+            // ffn.cpp:132 + self_decoder.cpp:111 h = act.Wd^T + resid, then the next layer's resid = h; h = rmsnorm(h)
+            const void *next_gamma = l + 1 < c.num_layers ? dec->layers[l + 1].attn_norm_gamma : nullptr;
+            TIMED(LLMIE_OP_ATTN_NORM, splitk_rownorm(sk, scale_of(w.down), nullptr, resid, static_cast<const half_t *>(next_gamma),
+                                                     c.rms_eps, hh, st));
+        }
+        return LLMIE_OK;
+    }
+
     for (int l = 0; l < c.num_layers; ++l) {
         const llmie_layer_weights &w = dec->layers[l];
         // self_decoder.cpp:77  resid = h ; h = rmsnorm(h)

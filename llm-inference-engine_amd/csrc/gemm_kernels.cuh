@@ -21,7 +21,6 @@ namespace llmie {
 
 enum : int { EPI_NONE = 0, EPI_SWIGLU = 1 };
 
-typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------
 // Decode GEMV family:  y[m, r] = sum_k xn[m,k] * W[r,k]   (fp16, M <= 8 tokens, W row-major [N,K])
@@ -50,7 +49,6 @@ struct GemvArgs {
 // int8 / int4 are de-quantised in registers with the fp16 "magic number" trick (0x6400 | u = 1024 + u exactly),
 // two weights per v_perm/v_and + one packed subtract, and fed to v_dot2_f32_f16 like the fp16 stream; the
 // per-row (int8) or per-(row, group) (int4) scale is applied to the fp32 partial sum.
-typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
 
 template <int WBITS> struct WFmt;
 template <> struct WFmt<16> { static constexpr int XE = 1; };  // half8 of x per chunk
@@ -601,7 +599,7 @@ __global__ __launch_bounds__(256) void skinny_splitk_kernel(const half_t *__rest
     constexpr int CPR = BK / 8;                    // 16-byte chunks per tile row
     // activation staging group: G sub-blocks at once (all their loads in flight together, one barrier pair per group)
     // G * ROWS * BK * 2 bytes <= 32 KB of LDS so that 4-5 workgroups stay resident per CU (the whole grid in one round)
-    constexpr int G = (WBITS == 16) ? (MT == 1 ? 8 : (MT == 2 ? 4 : 2)) : (MT == 1 ? 4 : (MT == 2 ? 2 : 1));
+    constexpr int G = 32768 / (ROWS * BK * 2) >= 1 ? 32768 / (ROWS * BK * 2) : 1;   // fp16: 8,4,2,2,1.. ; int8: 4,2,1,1,..
     constexpr int GCH = G * ROWS * CPR;               // 16-byte chunks per group
     constexpr int XCH = (GCH + 255) / 256;            // staging chunks per thread
     __shared__ __attribute__((aligned(16))) half_t xs[G][ROWS * BK];
@@ -623,7 +621,13 @@ __global__ __launch_bounds__(256) void skinny_splitk_kernel(const half_t *__rest
     const int b_begin = ks * blocks_per_slice, b_end = min(nblocks, b_begin + blocks_per_slice);
 
     // weight fragments: ring of 4 sub-blocks (16 loads in flight per lane), refilled as soon as a slot is consumed
-    constexpr int R = G < 4 ? G : 4;  // ring depth (G % R == 0 so slot indices stay compile-time)
+#ifndef LLMIE_SK_RING_MIN
+#define LLMIE_SK_RING_MIN 2
+#endif
+    // ring depth: 4 sub-blocks, but no deeper than the staging group unless that is a single sub-block (measured on
+    // MI355X: a 4-deep ring with G = 2 costs registers/occupancy and ~4 us per launch at M = 32)
+    constexpr int R = G >= 4 ? 4 : (G > LLMIE_SK_RING_MIN ? G : LLMIE_SK_RING_MIN);
+    constexpr int U = G > R ? G : R;     // main-loop unroll: ring slot (i % R) and group slot (i % G) both compile-time
     uint4_t a[R][4];
     half8_t xr[XCH];
     auto load_a = [&](int blk, uint4_t(&dst)[4]) {
@@ -700,22 +704,24 @@ __global__ __launch_bounds__(256) void skinny_splitk_kernel(const half_t *__rest
 #pragma unroll
     for (int i = 0; i < R; ++i)
         if (i < nb) load_a(b_begin + i, a[i]);
-    static_assert(G % R == 0, "group size vs ring depth");
-    for (int g0 = 0; g0 < nb; g0 += G) {
-        store_xg();
-        __syncthreads();
-        if (g0 + G < nb) load_xg(b_begin + g0 + G, b_end - 1);  // next group's activations in flight under the MFMAs
+    static_assert(U % R == 0 && U % G == 0, "unroll vs ring depth / group size");
+    for (int u0 = 0; u0 < nb; u0 += U) {
 #pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const int b = g0 + i;  // wave-uniform
+        for (int i = 0; i < U; ++i) {
+            const int b = u0 + i;  // wave-uniform
             if (b < nb) {
+                if (i % G == 0) {  // group boundary: publish the staged activations, start fetching the next group
+                    if (b) __syncthreads();  // previous group consumed by every wave
+                    store_xg();
+                    __syncthreads();
+                    if (b + G < nb) load_xg(b_begin + b + G, b_end - 1);
+                }
                 uint4_t frag[4];
                 transpose_w(a[i % R], frag);
                 if (b + R < nb) load_a(b_begin + b + R, a[i % R]);  // ring slot free again
-                compute(frag, i);
+                compute(frag, i % G);
             }
         }
-        __syncthreads();  // group consumed before the next store_xg overwrites it
     }
     // rows past M were computed on clamped (duplicate) activations: never stored
 #pragma unroll

@@ -173,10 +173,15 @@ static float *splitk_scratch(size_t floats) {
     return buf;
 }
 
-// split-K skinny MFMA path: 8 < M (any M, processed 64 rows of x per pass); wbits 16 or 8
-int linear_splitk(int wbits, const half_t *x, const void *W, const half_t *scale, half_t *y, int M, int K, int N, int epi,
-                  const half_t *bias, const half_t *residual, hipStream_t st) {
+// split-K skinny MFMA path, first half: partial products of one pass (8 < M <= 128) into the library's fp32 slabs
+// [KS][M][N].  The slabs stay valid until the next split-K launch on the stream; the consumer (finalize kernel,
+// splitk_rownorm, or the decode attention reading q/k/v straight from the slabs) must be enqueued before it.
+int linear_splitk_partial(int wbits, const half_t *x, const void *W, int M, int K, int N, hipStream_t st, SplitKSlabs *out) {
     const int bk = wbits == 16 ? 128 : 256;  // k per sub-block (4 weight loads per lane)
+    if (M < 1 || M > 128 || K % bk || K < 512 || (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) % 16) {
+        set_error("linear(split-K): unsupported shape M=%d K=%d (bits=%d)", M, K, wbits);
+        return LLMIE_ERR_UNSUPPORTED;
+    }
     const int tiles = (N + 63) / 64, total_blocks = K / bk;
     static const int target = env_int("LLMIE_SPLITK_TARGET_WGS", 512);
     // K slices: enough workgroups to fill the chip, but >= 4 sub-blocks per slice (the weight ring depth) and as few
@@ -184,34 +189,137 @@ int linear_splitk(int wbits, const half_t *x, const void *W, const half_t *scale
     int KS = 1;
     while (KS < 16 && tiles * KS < target && total_blocks / (KS * 2) >= 4) KS *= 2;
     const int spp = (total_blocks + KS - 1) / KS;
-    const int out_n = epi == EPI_SWIGLU ? N / 2 : N;
-    for (int m0 = 0; m0 < M; m0 += 64) {
-        const int mc = M - m0 < 64 ? M - m0 : 64;
-        float *slab = splitk_scratch(static_cast<size_t>(KS) * mc * N);
-        if (!slab) {
-            set_error("linear: split-K scratch allocation failed");
-            return LLMIE_ERR_WORKSPACE;
-        }
-        const half_t *xs = x + static_cast<size_t>(m0) * K;
-        const int mt = (mc + 15) / 16;
-        const dim3 grid(tiles * KS);
+    float *slab = splitk_scratch(static_cast<size_t>(KS) * M * N);
+    if (!slab) {
+        set_error("linear: split-K scratch allocation failed");
+        return LLMIE_ERR_WORKSPACE;
+    }
+    const int mt = (M + 15) / 16;
+    const dim3 grid(tiles * KS);
 #define LLMIE_SK(MT_)                                                                                          \
-    (wbits == 16 ? skinny_splitk_kernel<MT_, 16><<<grid, 256, 0, st>>>(xs, W, slab, mc, K, N, KS, spp)             \
-                 : skinny_splitk_kernel<MT_, 8><<<grid, 256, 0, st>>>(xs, W, slab, mc, K, N, KS, spp))
-        switch (mt) {
-            case 1: LLMIE_SK(1); break;
-            case 2: LLMIE_SK(2); break;
-            case 3: LLMIE_SK(3); break;
-            default: LLMIE_SK(4); break;
-        }
+    (wbits == 16 ? skinny_splitk_kernel<MT_, 16><<<grid, 256, 0, st>>>(x, W, slab, M, K, N, KS, spp)              \
+                 : skinny_splitk_kernel<MT_, 8><<<grid, 256, 0, st>>>(x, W, slab, M, K, N, KS, spp))
+    switch (mt) {
+        case 1: LLMIE_SK(1); break;
+        case 2: LLMIE_SK(2); break;
+        case 3: LLMIE_SK(3); break;
+        case 4: LLMIE_SK(4); break;
+        case 5: LLMIE_SK(5); break;
+        case 6: LLMIE_SK(6); break;
+        case 7: LLMIE_SK(7); break;
+        default: LLMIE_SK(8); break;
+    }
 #undef LLMIE_SK
+    out->slab = slab;
+    out->KS = KS;
+    out->M = M;
+    out->N = N;
+    return launch_status("linear(split-K)");
+}
+
+// split-K skinny MFMA path: 8 < M (any M, 128 rows of x per pass); wbits 16 or 8
+int linear_splitk(int wbits, const half_t *x, const void *W, const half_t *scale, half_t *y, int M, int K, int N, int epi,
+                  const half_t *bias, const half_t *residual, hipStream_t st) {
+    static const int mpass = env_int("LLMIE_SPLITK_PASS_M", 128);  // activation rows per pass (16 per MFMA tile, <= 128)
+    const int out_n = epi == EPI_SWIGLU ? N / 2 : N;
+    for (int m0 = 0; m0 < M; m0 += mpass) {
+        const int mc = M - m0 < mpass ? M - m0 : mpass;
+        SplitKSlabs sk;
+        const int rc = linear_splitk_partial(wbits, x + static_cast<size_t>(m0) * K, W, mc, K, N, st, &sk);
+        if (rc) return rc;
         const size_t total = static_cast<size_t>(mc) * out_n;
         int fgrid = static_cast<int>((total + 255) / 256);
         if (fgrid > 2048) fgrid = 2048;
-        skinny_finalize_kernel<<<fgrid, 256, 0, st>>>(slab, y + static_cast<size_t>(m0) * out_n, mc, N, KS, scale, bias,
+        skinny_finalize_kernel<<<fgrid, 256, 0, st>>>(sk.slab, y + static_cast<size_t>(m0) * out_n, mc, N, sk.KS, scale, bias,
                                                       residual ? residual + static_cast<size_t>(m0) * N : nullptr, epi);
     }
     return launch_status("linear(split-K)");
+}
+
+// Row epilogue of a split-K projection fused with the residual stream and the next RMSNorm (one launch instead of
+// finalize + launchFusedAddBiasResidualAndRMSNorm, add_residual_and_rmsnorm.cu:43-121 semantics):
+//   t = sum_ks slab[ks][m][:] (* wscale[:]) + resid[m][:];   resid[m][:] = t;   t += bias;
+//   y[m][:] = gamma ? t * rsqrt(mean(t^2) + eps) * gamma : t
+// One 1024-thread workgroup per row (a thread owns 4 columns per 4096; every slab load of the row is in flight at
+// once: the slabs were just written by other XCDs, so each load is a full memory round trip).  N <= 8192, N % 4 == 0.
+static __global__ __launch_bounds__(1024) void splitk_rownorm_kernel(const float *__restrict__ slab, int KS, int M, int N,
+                                                                     const half_t *__restrict__ wscale,
+                                                                     const half_t *__restrict__ bias, half_t *resid,
+                                                                     const half_t *__restrict__ gamma, float eps, half_t *y) {
+    __shared__ float red[16];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const size_t slab_sz = static_cast<size_t>(M) * N;
+    constexpr int NC = 2;
+    floatx4 v[NC];
+    half4_t r4[NC];
+    int col[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        col[i] = (i * 1024 + tid) * 4;
+        v[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+        if (col[i] < N) r4[i] = *reinterpret_cast<const half4_t *>(resid + static_cast<size_t>(m) * N + col[i]);
+    }
+    for (int k0 = 0; k0 < KS; k0 += 8) {
+        floatx4 t[8][NC];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+                if (col[i] < N)
+                    t[kk][i] = *reinterpret_cast<const floatx4 *>(slab + static_cast<size_t>(min(k0 + kk, KS - 1)) * slab_sz +
+                                                                  static_cast<size_t>(m) * N + col[i]);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+            if (k0 + kk < KS) {
+#pragma unroll
+                for (int i = 0; i < NC; ++i) v[i] += t[kk][i];
+            }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        if (col[i] < N) {
+            const int c = col[i];
+            half4_t o4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = v[i][e];
+                if (wscale) t *= to_f32(wscale[c + e]);
+                // same roundings as the unfused sequence: projection output -> fp16, residual sum -> fp16
+                t = to_f32(from_f32<half_t>(t)) + to_f32(r4[i][e]);
+                o4[e] = from_f32<half_t>(t);
+                t = to_f32(o4[e]);
+                if (bias) t += to_f32(bias[c + e]);
+                v[i][e] = t;
+                ss = fmaf(t, t, ss);
+            }
+            *reinterpret_cast<half4_t *>(resid + static_cast<size_t>(m) * N + c) = o4;
+        }
+    }
+    float inv = 1.f;
+    if (gamma) inv = rsqrtf(block_sum<16>(ss, red) / static_cast<float>(N) + eps);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        if (col[i] < N) {
+            const int c = col[i];
+            half4_t o4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o4[e] = from_f32<half_t>(gamma ? v[i][e] * inv * to_f32(gamma[c + e]) : v[i][e]);
+            *reinterpret_cast<half4_t *>(y + static_cast<size_t>(m) * N + c) = o4;
+        }
+    }
+}
+
+bool splitk_rownorm_eligible(int N) { return N % 4 == 0 && N <= 8192; }
+
+int splitk_rownorm(const SplitKSlabs &sk, const half_t *wscale, const half_t *bias, half_t *resid, const half_t *gamma,
+                   float eps, half_t *y, hipStream_t st) {
+    if (!splitk_rownorm_eligible(sk.N)) {
+        set_error("splitk_rownorm: N=%d not supported", sk.N);
+        return LLMIE_ERR_UNSUPPORTED;
+    }
+    splitk_rownorm_kernel<<<sk.M, 1024, 0, st>>>(sk.slab, sk.KS, sk.M, sk.N, wscale, bias, resid, gamma, eps, y);
+    return launch_status("splitk_rownorm");
 }
 
 // does the GEMV family take (M, K)?  (K-split register budget, else the LDS fallback's 64 KB)

@@ -17,6 +17,15 @@ int linear_f16_nk_norm(const half_t *x, const half_t *W, half_t *y, int M, int K
                        const half_t *residual, const half_t *gamma, const half_t *pre_bias, float eps, hipStream_t st);
 
 // split-K skinny MFMA GEMM (fp16 or int8 weights), any M processed 64 tokens per pass; epi may be SwiGLU; linear.hip
+// partial products of a split-K projection: fp32 slabs [KS][M][N] in library-owned scratch (see linear.hip)
+struct SplitKSlabs {
+    float *slab;
+    int KS, M, N;
+};
+int linear_splitk_partial(int wbits, const half_t *x, const void *W, int M, int K, int N, hipStream_t st, SplitKSlabs *out);
+bool splitk_rownorm_eligible(int N);
+int splitk_rownorm(const SplitKSlabs &sk, const half_t *wscale, const half_t *bias, half_t *resid, const half_t *gamma,
+                   float eps, half_t *y, hipStream_t st);
 int linear_splitk(int wbits, const half_t *x, const void *W, const half_t *scale, half_t *y, int M, int K, int N, int epi,
                   const half_t *bias, const half_t *residual, hipStream_t st);
 // quantised-weight (int8 / int4) decode GEMV on the K-split kernel; defined in linear.hip
@@ -33,7 +42,9 @@ int decoder_mha_rope(const void *qkv, const void *qkv_bias, void *k_cache, void 
                      int head_num, int kv_head_num, int head_size, int max_seq_len, int step, const int32_t *step_dev,
                      void *workspace, size_t workspace_bytes, const float2 *rope, int rot_dim,
                      int32_t *tickets /* [batch,kvh] zeroed arrival counters: in-launch merge; null = merge kernel */,
-                     llmie_dtype dtype, hipStream_t st);
+                     llmie_dtype dtype, hipStream_t st,
+                     const SplitKSlabs *qkv_slabs = nullptr /* q/k/v read from the QKV projection's split-K slabs (qkv unused) */,
+                     const half_t *qkv_wscale = nullptr);
 
 // prefill attention (RoPE + KV append + flash attention) on the packed QKV buffer; prefill.hip
 int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, half_t *k_cache, half_t *v_cache, half_t *out,

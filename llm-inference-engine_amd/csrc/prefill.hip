@@ -16,7 +16,6 @@
 
 namespace llmie {
 
-typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 // token -> (batch, position in its sequence) from the exclusive prefix cum[batch+1]
 __device__ __forceinline__ void locate_token(const int32_t *__restrict__ cum, int batch, int t, int &b, int &pos) {

@@ -59,6 +59,12 @@ CASES = [
     ("7Bgeom_fp16_bs4", torch.float16, 32, 32, 128, 11008, 1, 4, 160, [130], False),
     ("gqa_fp16_bs2", torch.float16, 16, 4, 128, 1024, 2, 2, 96, [50], True),
     ("7Bgeom_fp16_bs20", torch.float16, 32, 32, 128, 11008, 1, 20, 64, [33], False),
+    # fused batch path (split-K slabs consumed by the attention / row-norm launches): several layers, biases, GQA,
+    # more than one 16-row MFMA tile, a context spanning several attention chunks; bs 130 takes the unfused path
+    ("7Bgeom_fp16_bs20_L2", torch.float16, 32, 32, 128, 11008, 2, 20, 64, [33], False),
+    ("gqa_fp16_bs40_L3_bias", torch.float16, 16, 4, 128, 1024, 3, 40, 320, [300], True),
+    ("mha64_fp16_bs128_L2_bias", torch.float16, 8, 8, 64, 768, 2, 128, 48, [17], True),
+    ("mha64_fp16_bs130_L2_bias", torch.float16, 8, 8, 64, 768, 2, 130, 48, [17], True),
 ]
 
 
