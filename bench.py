@@ -281,7 +281,7 @@ def main():
                 step_dev.fill_(max(1, S - P + 1))
                 one_step()  # untimed: re-warm after the fill
                 step_dev.fill_(max(1, S - P + 1))
-                dec.profile_begin(P * (cfg["num_layers"] * 8 + 4))
+                dec.profile_begin(P * (cfg["num_layers"] * 12 + 8))
                 for _ in range(P):
                     one_step()
                 prof = dec.profile_end()

@@ -34,7 +34,7 @@ struct QkvSlabs {
     const float *slab;
     int KS;
     size_t stride;          // floats between slabs (= batch * qkv_dim)
-    const half_t *wscale;   // per-output-channel weight scale (int8) or null
+    SlabScale sc;           // scales of the projection's weight format (int8: per channel; fp8: channel x token)
 };
 
 // Merge of the per-split (m, l, o[d]) partials of one (batch, head) for output dim d: 16 splits per round,
@@ -116,6 +116,8 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
     const bool wg_has_new = t_new >= t0 && t_new < t0 + CHUNK;  // workgroup-uniform
     floatx4 spart[LROUNDS][4];
     half4_t sscale[LROUNDS];
+    floatx4 sscalef[LROUNDS];
+    const float xs_b = (qs.slab && qs.sc.wf) ? qs.sc.xs[b] : 1.f;
     size_t scol[LROUNDS];
     bool sact[LROUNDS];
     if (qs.slab) {
@@ -131,7 +133,8 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
                     spart[lr][kk] = *reinterpret_cast<const floatx4 *>(p + static_cast<size_t>(min(kk, qs.KS - 1)) * qs.stride);
-                if (qs.wscale) sscale[lr] = *reinterpret_cast<const half4_t *>(qs.wscale + scol[lr]);
+                if (qs.sc.wh) sscale[lr] = *reinterpret_cast<const half4_t *>(qs.sc.wh + scol[lr]);
+                if (qs.sc.wf) sscalef[lr] = *reinterpret_cast<const floatx4 *>(qs.sc.wf + scol[lr]);
             }
         }
     } else {
@@ -184,7 +187,12 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
                 for (int k = 4; k < qs.KS; ++k) f += *reinterpret_cast<const floatx4 *>(p + static_cast<size_t>(k) * qs.stride);
                 const int item = lr * NT + threadIdx.x;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) qkvlds[item * 4 + e] = from_f32<T>(qs.wscale ? f[e] * to_f32(sscale[lr][e]) : f[e]);
+                for (int e = 0; e < 4; ++e) {
+                    float v = f[e];
+                    if (qs.sc.wh) v *= to_f32(sscale[lr][e]);          // the arithmetic of SlabScale::apply
+                    if (qs.sc.wf) v *= sscalef[lr][e] * xs_b;
+                    qkvlds[item * 4 + e] = from_f32<T>(v);
+                }
             }
         }
         __syncthreads();
@@ -571,14 +579,17 @@ static int decoder_mha_impl(const T *qkv, const T *bias, T *k_cache, T *v_cache,
 int decoder_mha_rope(const void *qkv, const void *qkv_bias, void *k_cache, void *v_cache, void *out, int layer, int batch,
                      int head_num, int kv_head_num, int head_size, int max_seq_len, int step, const int32_t *step_dev,
                      void *workspace, size_t workspace_bytes, const float2 *rope, int rot_dim, int32_t *tickets,
-                     llmie_dtype dtype, hipStream_t st, const SplitKSlabs *qkv_slabs, const half_t *qkv_wscale) {
-    QkvSlabs qs{nullptr, 0, 0, nullptr};
-    if (qkv_slabs && (reinterpret_cast<uintptr_t>(qkv_wscale) % 8 || reinterpret_cast<uintptr_t>(qkv_slabs->slab) % 16 ||
+                     llmie_dtype dtype, hipStream_t st, const SplitKSlabs *qkv_slabs, const SlabScale *qkv_scale) {
+    QkvSlabs qs{nullptr, 0, 0, SlabScale{nullptr, nullptr, nullptr}};
+    const SlabScale no_scale{nullptr, nullptr, nullptr};
+    const SlabScale &qsc = qkv_scale ? *qkv_scale : no_scale;
+    if (qkv_slabs && (reinterpret_cast<uintptr_t>(qsc.wh) % 8 || reinterpret_cast<uintptr_t>(qsc.wf) % 16 ||
+                      reinterpret_cast<uintptr_t>(qkv_slabs->slab) % 16 ||
                       (static_cast<size_t>(qkv_slabs->M) * qkv_slabs->N) % 4)) {
-        set_error("decoder_mha: q/k/v from split-K slabs needs 16-byte aligned slabs and an 8-byte aligned scale vector");
+        set_error("decoder_mha: q/k/v from split-K slabs needs 16-byte aligned slabs and aligned scale vectors");
         return LLMIE_ERR_UNSUPPORTED;
     }
-    if (qkv_slabs) qs = QkvSlabs{qkv_slabs->slab, qkv_slabs->KS, static_cast<size_t>(qkv_slabs->M) * qkv_slabs->N, qkv_wscale};
+    if (qkv_slabs) qs = QkvSlabs{qkv_slabs->slab, qkv_slabs->KS, static_cast<size_t>(qkv_slabs->M) * qkv_slabs->N, qsc};
     if (dtype == LLMIE_F32)
         return decoder_mha_impl<float>((const float *)qkv, (const float *)qkv_bias, (float *)k_cache, (float *)v_cache,
                                        (float *)out, layer, batch, head_num, kv_head_num, head_size, max_seq_len, step,
@@ -611,11 +622,11 @@ extern "C" int llmie_decoder_mha(const void *qkv, const void *qkv_bias, void *k_
     if (dtype == LLMIE_F32)
         return decoder_mha_impl<float>((const float *)qkv, (const float *)qkv_bias, (float *)k_cache, (float *)v_cache,
                                        (float *)out, layer, batch, head_num, kv_head_num, head_size, max_seq_len, step,
-                                       step_dev, workspace, workspace_bytes, nullptr, 0, nullptr, QkvSlabs{nullptr, 0, 0, nullptr}, as_stream(stream));
+                                       step_dev, workspace, workspace_bytes, nullptr, 0, nullptr, QkvSlabs{nullptr, 0, 0, SlabScale{nullptr, nullptr, nullptr}}, as_stream(stream));
     if (dtype == LLMIE_F16)
         return decoder_mha_impl<half_t>((const half_t *)qkv, (const half_t *)qkv_bias, (half_t *)k_cache,
                                         (half_t *)v_cache, (half_t *)out, layer, batch, head_num, kv_head_num, head_size,
-                                        max_seq_len, step, step_dev, workspace, workspace_bytes, nullptr, 0, nullptr, QkvSlabs{nullptr, 0, 0, nullptr}, as_stream(stream));
+                                        max_seq_len, step, step_dev, workspace, workspace_bytes, nullptr, 0, nullptr, QkvSlabs{nullptr, 0, 0, SlabScale{nullptr, nullptr, nullptr}}, as_stream(stream));
     LLMIE_UNSUPPORTED("decoder_mha: dtype %d", (int)dtype);
 }
 

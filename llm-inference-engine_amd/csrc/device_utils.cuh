@@ -103,4 +103,29 @@ __device__ __forceinline__ float dot8(half8_t a, half8_t b, float acc) {
     return acc;
 }
 
+// 4 floats -> 4 e4m3fn bytes (OCP fp8, the gfx950 conversion), saturating
+__device__ __forceinline__ unsigned int pack4_e4m3(float a, float b, float c, float d) {
+    // saturate to the e4m3fn range first: the conversion would produce NaN past 448
+    a = fminf(fmaxf(a, -448.f), 448.f);
+    b = fminf(fmaxf(b, -448.f), 448.f);
+    c = fminf(fmaxf(c, -448.f), 448.f);
+    d = fminf(fmaxf(d, -448.f), 448.f);
+    int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return static_cast<unsigned int>(v);
+}
+
+// scales a split-K slab consumer applies to the reduced value of output (m, n):
+//   fp16 weights: none;  int8: wh[n] (fp16 per output channel);  fp8: wf[n] * xs[m] (fp32 weight-row x token scales)
+struct SlabScale {
+    const half_t *wh;
+    const float *wf;
+    const float *xs;
+    __device__ __forceinline__ float apply(float v, int m, int n) const {
+        if (wh) return v * static_cast<float>(wh[n]);
+        if (wf) return v * (wf[n] * xs[m]);
+        return v;
+    }
+};
+
 }  // namespace llmie

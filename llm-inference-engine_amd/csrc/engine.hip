@@ -103,7 +103,8 @@ static size_t carve(const llmie_decoder_config *c, size_t *offs /*[10]*/) {
     offs[7] = k.take(static_cast<size_t>(c->max_seq_len) * (c->head_size / 2) * sizeof(float2));  // RoPE table
     offs[8] = k.take(static_cast<size_t>(c->max_batch) * c->kv_head_num * sizeof(int32_t));         // merge tickets
     const int kmax = c->inter_size > static_cast<int>(H) ? c->inter_size : static_cast<int>(H);
-    offs[9] = k.take(c->wfmt == LLMIE_W_FP8 ? llmie_linear_fp8_workspace_bytes(c->max_batch, kmax) : 256);
+    // fp8: three activation-quantisation units (normed input, attention output, SwiGLU output), see decoder_forward
+    offs[9] = k.take(c->wfmt == LLMIE_W_FP8 ? 3 * llmie_linear_fp8_workspace_bytes(c->max_batch, kmax) : 256);
     return k.off;
 }
 
@@ -316,9 +317,10 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
     const bool hs_ok = c.head_size == 32 || c.head_size == 64 || c.head_size == 128 || c.head_size == 256;
     const bool rep_ok = rep == 1 || rep == 2 || rep == 4 || rep == 8;
     const int wbits = c.wfmt == LLMIE_W_F16 ? 16 : (c.wfmt == LLMIE_W_INT8 ? 8 : (c.wfmt == LLMIE_W_INT4 ? 4 : 0));
+    const bool fp8 = c.wfmt == LLMIE_W_FP8;
     const bool gemv_ok = wbits == 16 ? gemv_f16_eligible(batch, H, h, dec->layers[0].qkv.data)
-                                     : (wbits != 0 && ksplit_eligible(batch, H, wbits));
-    if (!fused_off && c.dtype == LLMIE_F16 && wbits != 0 && hs_ok && rep_ok && H % 8 == 0 && gemv_ok) {
+                                     : ((wbits != 0 || fp8) && ksplit_eligible(batch, H, fp8 ? 8 : wbits));
+    if (!fused_off && c.dtype == LLMIE_F16 && (wbits != 0 || fp8) && hs_ok && rep_ok && H % 8 == 0 && gemv_ok) {
         hipStream_t st = as_stream(stream);
         // In-launch merge of the attention partials (ticket + agent-scope release/acquire) measured SLOWER than the
         // separate 4.8 us merge kernel on MI355X (2.97 vs 2.81 ms per token: every workgroup pays the release fence),
@@ -327,6 +329,20 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
         // y = [swiglu]( rmsnorm(x + pre_bias)*gamma . W^T ) + residual on the streaming GEMV of the weight format
         auto lin = [&](const void *x, const llmie_matrix &w, void *y, int K, int N, int epi, const void *residual,
                        const void *gamma, const void *pre_bias) -> int {
+            if (fp8) {
+                // e4m3 weights x per-token e4m3 activations; the GEMV handles K rows that fit its register budget,
+                // longer ones (down projection at batch > 2) take the MFMA launch sequence of llmie_linear_fp8
+                if (ksplit_eligible(batch, K, 8))
+                    return linear_fp8_gemv((const half_t *)x, (const uint8_t *)w.data, (const float *)w.scale, (half_t *)y, batch,
+                                           K, N, epi, nullptr, (const half_t *)residual, (const half_t *)gamma,
+                                           (const half_t *)pre_bias, c.rms_eps, st);
+                if (epi != EPI_NONE_ || gamma) {
+                    set_error("engine: fp8 projection K=%d at batch %d has no fused form", K, batch);
+                    return LLMIE_ERR_UNSUPPORTED;
+                }
+                return llmie_linear_fp8(x, (const uint8_t *)w.data, (const float *)w.scale, y, batch, K, N, nullptr, residual,
+                                        dec->fp8_ws, dec->fp8_ws_bytes, stream);
+            }
             if (wbits == 16) {
                 if (gamma)
                     return linear_f16_nk_norm((const half_t *)x, (const half_t *)w.data, (half_t *)y, batch, K, N, epi, nullptr,
@@ -353,41 +369,61 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
         return LLMIE_OK;
     }
 
-    // ---- fused batch decode path (8 < batch <= 128, fp16 or int8 weights): 8 launches per layer (+ the attention merge
-    // when the context spans several chunks) instead of 11-12.  Every projection is a split-K MFMA launch that leaves
-    // fp32 partial slabs; the consumer of each slab does the reduction:
+    // ---- fused batch decode path (8 < batch <= 128; fp16, int8 or fp8 weights): 8 launches per layer (+ the attention
+    // merge when the context spans several chunks) instead of 11-12.  Every projection is a split-K MFMA launch that
+    // leaves fp32 partial slabs; the consumer of each slab does the reduction:
     //   qkv slabs            -> read directly by the attention launch (q rows, new k/v rows; + scale, bias, RoPE, append)
     //   o / down slabs       -> splitk_rownorm: reduction + residual stream update + the NEXT RMSNorm in one launch
     //   gate_up slabs        -> finalize with the SwiGLU epilogue
     // (each small dependent launch costs ~4.5 us on MI355X, a third of a batch-32 int8 layer before this fusion)
+    // fp8: activations enter every projection as per-token e4m3; the row kernel emits them directly for the qkv and
+    // gate_up inputs, the attention and SwiGLU outputs take a quantize_rows launch each (10 launches per layer).
     static const int batch_fused_off = getenv("LLMIE_NO_FUSED_BATCH") ? 1 : 0;
-    if (!batch_fused_off && c.dtype == LLMIE_F16 && (wbits == 16 || wbits == 8) && hs_ok && rep_ok && batch <= 128 &&
+    if (!batch_fused_off && c.dtype == LLMIE_F16 && (wbits == 16 || wbits == 8 || fp8) && hs_ok && rep_ok && batch <= 128 &&
         H % 256 == 0 && I % 256 == 0 && H >= 512 && I >= 512 && splitk_rownorm_eligible(H)) {
         hipStream_t st = as_stream(stream);
         half_t *hh = static_cast<half_t *>(h), *resid = reinterpret_cast<half_t *>(dec->resid);
-        auto scale_of = [&](const llmie_matrix &m) { return wbits == 8 ? static_cast<const half_t *>(m.scale) : nullptr; };
+        half_t *mha = reinterpret_cast<half_t *>(dec->mha), *act = reinterpret_cast<half_t *>(dec->act);
+        const int fmt = fp8 ? WF_FP8 : wbits;
+        const size_t unit = dec->fp8_ws_bytes, kmax = static_cast<size_t>(I > H ? I : H);
+        auto xq_of = [&](int u) { return fp8 ? reinterpret_cast<uint8_t *>(dec->fp8_ws) + u * unit : nullptr; };
+        auto xs_of = [&](int u) {
+            return fp8 ? reinterpret_cast<float *>(xq_of(u) + ((static_cast<size_t>(c.max_batch) * kmax + 255) & ~size_t(255))) : nullptr;
+        };
+        uint8_t *xqA = xq_of(0), *xqB = xq_of(1), *xqC = xq_of(2);
+        float *xsA = xs_of(0), *xsB = xs_of(1), *xsC = xs_of(2);
+        auto scale_of = [&](const llmie_matrix &m, const float *xs) {
+            if (fp8) return SlabScale{nullptr, static_cast<const float *>(m.scale), xs};
+            return SlabScale{wbits == 8 ? static_cast<const half_t *>(m.scale) : nullptr, nullptr, nullptr};
+        };
         // self_decoder.cpp:77 (first layer only: later ones get it from the previous layer's down-projection epilogue)
         TIMED(LLMIE_OP_ATTN_NORM, llmie_rmsnorm(h, dec->resid, dec->layers[0].attn_norm_gamma, c.rms_eps, batch, H, dt, stream));
+        if (fp8) TIMED(LLMIE_OP_ATTN_NORM, quantize_rows_fp8(hh, xqA, xsA, batch, H, st));
         for (int l = 0; l < c.num_layers; ++l) {
             const llmie_layer_weights &w = dec->layers[l];
+            const bool last = l + 1 == c.num_layers;
+            const void *xin = fp8 ? static_cast<const void *>(xqA) : hh;
             SplitKSlabs sk;
-            TIMED(LLMIE_OP_QKV_GEMM, linear_splitk_partial(wbits, hh, w.qkv.data, batch, H, QKV, st, &sk));
+            TIMED(LLMIE_OP_QKV_GEMM, linear_splitk_partial(fmt, xin, w.qkv.data, batch, H, QKV, st, &sk));
+            const SlabScale qsc = scale_of(w.qkv, xsA);
             TIMED(LLMIE_OP_MHA, decoder_mha_rope(nullptr, w.qkv.bias, k_cache, v_cache, dec->mha, l, batch, c.head_num,
                                                  c.kv_head_num, c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws,
-                                                 dec->attn_ws_bytes, dec->rope_table, c.rotary_dim, nullptr, dt, st, &sk,
-                                                 scale_of(w.qkv)));
-            TIMED(LLMIE_OP_O_GEMM, linear_splitk_partial(wbits, reinterpret_cast<const half_t *>(dec->mha), w.o.data, batch, H, H, st, &sk));
+                                                 dec->attn_ws_bytes, dec->rope_table, c.rotary_dim, nullptr, dt, st, &sk, &qsc));
+            if (fp8) TIMED(LLMIE_OP_O_GEMM, quantize_rows_fp8(mha, xqB, xsB, batch, H, st));
+            TIMED(LLMIE_OP_O_GEMM, linear_splitk_partial(fmt, fp8 ? static_cast<const void *>(xqB) : mha, w.o.data, batch, H, H, st, &sk));
             // self_decoder.cpp:92  h += resid; resid = h; h += o.bias; h = rmsnorm(h, ffn_gamma)
-            TIMED(LLMIE_OP_FFN_NORM, splitk_rownorm(sk, scale_of(w.o), static_cast<const half_t *>(w.o.bias), resid,
-                                                    static_cast<const half_t *>(w.ffn_norm_gamma), c.rms_eps, hh, st));
-            TIMED(LLMIE_OP_GATE_UP_SWIGLU, linear_splitk(wbits, hh, w.gate_up.data, scale_of(w.gate_up),
-                                                         reinterpret_cast<half_t *>(dec->act), batch, H, 2 * I, EPI_SWIGLU_, nullptr,
-                                                         nullptr, st));
-            TIMED(LLMIE_OP_DOWN_GEMM, linear_splitk_partial(wbits, reinterpret_cast<const half_t *>(dec->act), w.down.data, batch, I, H, st, &sk));
+            TIMED(LLMIE_OP_FFN_NORM, splitk_rownorm(sk, scale_of(w.o, xsB), static_cast<const half_t *>(w.o.bias), resid,
+                                                    static_cast<const half_t *>(w.ffn_norm_gamma), c.rms_eps,
+                                                    fp8 ? nullptr : hh, xqA, xsA, st));
+            // ffn.cpp:105-122  act = silu(h.Wg^T) * (h.Wu^T)
+            TIMED(LLMIE_OP_GATE_UP_SWIGLU, linear_splitk_partial(fmt, xin, w.gate_up.data, batch, H, 2 * I, st, &sk));
+            TIMED(LLMIE_OP_GATE_UP_SWIGLU, splitk_finalize(sk, scale_of(w.gate_up, xsA), act, EPI_SWIGLU_, nullptr, nullptr, st));
+            if (fp8) TIMED(LLMIE_OP_DOWN_GEMM, quantize_rows_fp8(act, xqC, xsC, batch, I, st));
+            TIMED(LLMIE_OP_DOWN_GEMM, linear_splitk_partial(fmt, fp8 ? static_cast<const void *>(xqC) : act, w.down.data, batch, I, H, st, &sk));
             // ffn.cpp:132 + self_decoder.cpp:111 h = act.Wd^T + resid, then the next layer's resid = h; h = rmsnorm(h)
-            const void *next_gamma = l + 1 < c.num_layers ? dec->layers[l + 1].attn_norm_gamma : nullptr;
-            TIMED(LLMIE_OP_ATTN_NORM, splitk_rownorm(sk, scale_of(w.down), nullptr, resid, static_cast<const half_t *>(next_gamma),
-                                                     c.rms_eps, hh, st));
+            const void *next_gamma = last ? nullptr : dec->layers[l + 1].attn_norm_gamma;
+            TIMED(LLMIE_OP_ATTN_NORM, splitk_rownorm(sk, scale_of(w.down, xsC), nullptr, resid, static_cast<const half_t *>(next_gamma),
+                                                     c.rms_eps, (fp8 && !last) ? nullptr : hh, last ? nullptr : xqA, xsA, st));
         }
         return LLMIE_OK;
     }

@@ -59,10 +59,22 @@ __device__ __forceinline__ half2_t as_half2(unsigned int u) { return __builtin_b
 
 // dot of one 16-byte weight chunk with its activation chunk(s); x is in natural k order for 16/8 bit and in the
 // permuted order produced by permute_x_int4() for 4 bit.
-template <int WBITS>
+template <int WBITS, bool FP8 = false>
 __device__ __forceinline__ float chunk_dot(const uint4_t w, const half8_t (&x)[WFmt<WBITS>::XE], float acc) {
     if constexpr (WBITS == 16) {
         return dot8(__builtin_bit_cast(half8_t, w), x[0], acc);
+    } else if constexpr (WBITS == 8 && FP8) {
+        // OCP e4m3 -> packed fp16 is one gfx950 instruction per pair (v_cvt_scalef32_pk_f16_fp8, scale 1.0)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const half2_t wlo = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(w[i]), 1.0f, false);
+            const half2_t whi = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(w[i]), 1.0f, true);
+            const half8_t xv = x[i >> 1];
+            const int b = (i & 1) * 4;
+            acc = __builtin_amdgcn_fdot2(wlo, half2_t{xv[b], xv[b + 1]}, acc, false);
+            acc = __builtin_amdgcn_fdot2(whi, half2_t{xv[b + 2], xv[b + 3]}, acc, false);
+        }
+        return acc;
     } else if constexpr (WBITS == 8) {
         // bytes b0..b3 of a word -> halves (b0,b1), (b2,b3) as 1024 + (b ^ 0x80) = 1152 + int8
         const half2_t off = {static_cast<half_t>(1152.f), static_cast<half_t>(1152.f)};
@@ -115,7 +127,10 @@ __device__ __forceinline__ half8_t permute_x_int4(const half8_t v) {
 // add their partial sums through a double-buffered LDS slot.
 // Measured fp16 (tools/gemv_bench.hip, MI355X, incl. ~1 us launch gap): QKV 100.7 MB 16.7 us, O 33.6 MB
 // 7.6 us, down 90.2 MB 16.1 us, LM head 262 MB 42 us = 6.0 / 4.4 / 5.6 / 6.2 TB/s.
-template <int M, int RPW, int XC, int WBITS, bool DB = false>
+// FP8 (WBITS == 8): e4m3 weights with fp32 per-row scales, and the activation row is quantised per token to the e4m3
+// grid in the prologue (scale amax/448, exactly quantize_rows_fp8_kernel's arithmetic) so that the result equals the
+// fp8 MFMA path's  wscale[n] * xscale[m] * sum_k Wq[n,k] xq[m,k]  up to summation order.
+template <int M, int RPW, int XC, int WBITS, bool DB = false, bool FP8 = false>
 __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
     // DB (quantised weights): two weight register sets -- the next group's loads are issued BEFORE the current group's
     // de-quantise + dot phase (~2 us of VALU per group for int4), which would otherwise run with nothing in flight.
@@ -240,6 +255,41 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
 #pragma unroll
                 for (int e = 0; e < XE; ++e) xr[m][j][e] = permute_x_int4(xr[m][j][e]);
     }
+    __shared__ float amx[FP8 ? 4 : 1][M], xscale_sh[M];  // FP8: per-token activation amax / scale
+    if constexpr (FP8) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            float amax = 0.f;
+#pragma unroll
+            for (int j = 0; j < XC; ++j)
+#pragma unroll
+                for (int e = 0; e < XE; ++e)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(to_f32(xr[m][j][e][i])));
+            amax = wave_max(amax);
+            if (lane == 0) amx[wave][m] = amax;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const float amax = fmaxf(fmaxf(amx[0][m], amx[1][m]), fmaxf(amx[2][m], amx[3][m]));
+            const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+            if (tid == 0) xscale_sh[m] = sc;  // read in the epilogue, after at least one more barrier
+#pragma unroll
+            for (int j = 0; j < XC; ++j)
+#pragma unroll
+                for (int e = 0; e < XE; ++e)
+#pragma unroll
+                    for (int i = 0; i < 8; i += 2) {
+                        const float f0 = fminf(fmaxf(to_f32(xr[m][j][e][i]) / sc, -448.f), 448.f);
+                        const float f1 = fminf(fmaxf(to_f32(xr[m][j][e][i + 1]) / sc, -448.f), 448.f);
+                        const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(f0, f1, 0, false);
+                        const half2_t h = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(pk, 1.0f, false);
+                        xr[m][j][e][i] = h[0];
+                        xr[m][j][e][i + 1] = h[1];
+                    }
+        }
+    }
 
     auto step = [&](auto &wb, auto &wsc, auto &wbn, auto &wscn, const int cur, const int it) {
         const int nxt = cur + gridDim.x;
@@ -260,7 +310,7 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
 #pragma unroll
                 for (int j = 0; j < XC; ++j) {
                     if constexpr (WBITS == 4) sdot = fmaf(sc[j], chunk_dot<4>(wb[r][j], xr[m][j], 0.f), sdot);
-                    else sdot = chunk_dot<WBITS>(wb[r][j], xr[m][j], sdot);
+                    else sdot = chunk_dot<WBITS, FP8>(wb[r][j], xr[m][j], sdot);
                 }
                 acc[m][r] = sdot;
             }
@@ -281,7 +331,10 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
                 for (int r = 0; r < RPW; ++r) slot[wave * (M * RPW) + m * RPW + r] = acc[m][r];
         }
         __syncthreads();  // one barrier per iteration: the other parity slot is free for the next iteration
-        auto row_scale = [&](int row) { return (WBITS == 8) ? to_f32(scale[row]) : 1.0f; };
+        auto row_scale = [&](int row) {
+            if constexpr (FP8) return reinterpret_cast<const float *>(a.scale)[row];
+            else return (WBITS == 8) ? to_f32(scale[row]) : 1.0f;
+        };
         if (swiglu) {
             if (tid < M * (RPW / 2)) {
                 const int m = tid / (RPW / 2), q = tid % (RPW / 2);
@@ -293,8 +346,8 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
                         gt += slot[w * (M * RPW) + m * RPW + 2 * q];
                         up += slot[w * (M * RPW) + m * RPW + 2 * q + 1];
                     }
-                    gt *= row_scale(col);
-                    up *= row_scale(col + half_n);
+                    gt *= row_scale(col) * (FP8 ? xscale_sh[m] : 1.0f);
+                    up *= row_scale(col + half_n) * (FP8 ? xscale_sh[m] : 1.0f);
                     a.y[static_cast<size_t>(m) * out_n + col] = from_f32<half_t>((gt / (1.0f + expf(-gt))) * up);
                 }
             }
@@ -306,7 +359,7 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
                     float v = 0.f;
 #pragma unroll
                     for (int w = 0; w < 4; ++w) v += slot[w * (M * RPW) + m * RPW + r];
-                    v *= row_scale(col);
+                    v *= row_scale(col) * (FP8 ? xscale_sh[m] : 1.0f);
                     if (a.bias) v += to_f32(a.bias[col]);
                     if (a.residual) v += to_f32(a.residual[static_cast<size_t>(m) * N + col]);
                     a.y[static_cast<size_t>(m) * N + col] = from_f32<half_t>(v);
@@ -583,26 +636,33 @@ __device__ __forceinline__ half8_t dequant_i8x8(unsigned int w0, unsigned int w1
     return half8_t{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
 }
 
-template <int MT, int WBITS>
-__global__ __launch_bounds__(256) void skinny_splitk_kernel(const half_t *__restrict__ x, const void *__restrict__ W,
+// FP8 (WBITS == 8): e4m3 weights AND e4m3 activations (x is [M,K] bytes, quantised per token by the producer), fed to
+// v_mfma_f32_16x16x32_fp8_fp8 without any conversion; the scales (wscale[n] * xscale[m]) are applied by the slab consumer.
+template <int MT, int WBITS, bool FP8 = false>
+__global__ __launch_bounds__(256) void skinny_splitk_kernel(const void *__restrict__ xv, const void *__restrict__ W,
                                                             float *__restrict__ slab, int M, int K, int N, int KS,
                                                             int blocks_per_slice) {
-    // One sub-block = 4 weight loads per lane: fp16 BK = 128 (4 steps of 32), int8 BK = 256 (4 steps of 64).
+    // One sub-block = 4 weight loads per lane: fp16 BK = 128 (4 steps of 32), int8 / fp8 BK = 256 (4 steps of 64).
     // The activation tile [16*MT rows][BK] of the sub-block is staged in LDS (coalesced 16-byte loads, chunks
     // XOR-swizzled with the row so a fragment read -- 16 rows x one chunk column -- is conflict-free) and shared by
     // the 4 waves: B fragments are ds_read_b128 (measured: fragment-shaped global loads of x, even L1-resident,
     // bound the first versions of this kernel at ~90 cycles per wave-load).  Weight fragments go HBM -> VGPR with
     // the next sub-block's loads in flight while the current one is multiplied; x tiles are double buffered.
+    static_assert(!FP8 || WBITS == 8, "fp8 is an 8-bit format");
     constexpr int KSTEP = (WBITS == 16) ? 32 : 64;
     constexpr int BK = 4 * KSTEP;
     constexpr int ROWS = 16 * MT;
-    constexpr int CPR = BK / 8;                    // 16-byte chunks per tile row
+    constexpr int XB = FP8 ? 1 : 2;                // bytes per activation element
+    constexpr int RB = BK * XB;                    // bytes per tile row
+    constexpr int CPR = RB / 16;                   // 16-byte chunks per tile row
     // activation staging group: G sub-blocks at once (all their loads in flight together, one barrier pair per group)
-    // G * ROWS * BK * 2 bytes <= 32 KB of LDS so that 4-5 workgroups stay resident per CU (the whole grid in one round)
-    constexpr int G = 32768 / (ROWS * BK * 2) >= 1 ? 32768 / (ROWS * BK * 2) : 1;   // fp16: 8,4,2,2,1.. ; int8: 4,2,1,1,..
+    // G * ROWS * RB bytes <= 32 KB of LDS so that several workgroups stay resident per CU
+    constexpr int G = 32768 / (ROWS * RB) >= 1 ? (32768 / (ROWS * RB) > 8 ? 8 : 32768 / (ROWS * RB)) : 1;
     constexpr int GCH = G * ROWS * CPR;               // 16-byte chunks per group
     constexpr int XCH = (GCH + 255) / 256;            // staging chunks per thread
-    __shared__ __attribute__((aligned(16))) half_t xs[G][ROWS * BK];
+    __shared__ __attribute__((aligned(16))) unsigned char xs[G][ROWS * RB];
+    const unsigned char *x = static_cast<const unsigned char *>(xv);
+    const size_t x_row_bytes = static_cast<size_t>(K) * XB;
     // per-wave weight transposer: a sub-block of the wave's 16 rows is 16 x 256 B; it is LOADED row-contiguously
     // (one wave instruction = 4 rows x 256 B: full cache lines, DRAM-friendly -- fragment-shaped global loads of
     // 16 rows x 64 B capped this kernel at ~3.8 TB/s) and re-read as MFMA fragments through 4 KB of private LDS.
@@ -629,7 +689,7 @@ __global__ __launch_bounds__(256) void skinny_splitk_kernel(const half_t *__rest
     constexpr int R = G >= 4 ? 4 : (G > LLMIE_SK_RING_MIN ? G : LLMIE_SK_RING_MIN);
     constexpr int U = G > R ? G : R;     // main-loop unroll: ring slot (i % R) and group slot (i % G) both compile-time
     uint4_t a[R][4];
-    half8_t xr[XCH];
+    uint4_t xr[XCH];
     auto load_a = [&](int blk, uint4_t(&dst)[4]) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) dst[u] = load_nt(reinterpret_cast<const uint4_t *>(wp + wrow_off[u] + static_cast<size_t>(blk) * 256));
@@ -658,7 +718,7 @@ __global__ __launch_bounds__(256) void skinny_splitk_kernel(const half_t *__rest
             const int id = min(tid + 256 * i, GCH - 1);
             const int g = id / (ROWS * CPR), rem = id - g * (ROWS * CPR), row = rem / CPR, ch = rem - row * CPR;
             const int blk = min(blk0 + g, last_blk);
-            xr[i] = *reinterpret_cast<const half8_t *>(x + static_cast<size_t>(min(row, M - 1)) * K + static_cast<size_t>(blk) * BK + ch * 8);
+            xr[i] = *reinterpret_cast<const uint4_t *>(x + static_cast<size_t>(min(row, M - 1)) * x_row_bytes + static_cast<size_t>(blk) * RB + ch * 16);
         }
     };
     auto store_xg = [&]() {
@@ -667,7 +727,7 @@ __global__ __launch_bounds__(256) void skinny_splitk_kernel(const half_t *__rest
             const int id = tid + 256 * i;
             if (id < GCH) {
                 const int g = id / (ROWS * CPR), rem = id - g * (ROWS * CPR), row = rem / CPR, ch = rem - row * CPR;
-                *reinterpret_cast<half8_t *>(&xs[g][row * BK + ((ch ^ (row & 15)) << 3)]) = xr[i];
+                *reinterpret_cast<uint4_t *>(&xs[g][row * RB + ((ch ^ (row & 15)) << 4)]) = xr[i];
             }
         }
     };
@@ -683,16 +743,29 @@ __global__ __launch_bounds__(256) void skinny_splitk_kernel(const half_t *__rest
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {
                     const int row = 16 * j + r, ch = u * 4 + q;
-                    const half8_t bf = *reinterpret_cast<const half8_t *>(&xs[buf][row * BK + ((ch ^ (row & 15)) << 3)]);
+                    const half8_t bf = *reinterpret_cast<const half8_t *>(&xs[buf][row * RB + ((ch ^ (row & 15)) << 4)]);
                     acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[j], 0, 0, 0);
+                }
+            } else if constexpr (FP8) {
+                // the lane's 16 consecutive k of this 64-wide step: two fp8 MFMA operands, no conversion
+                const long a0 = (static_cast<long>(ab[u][1]) << 32) | ab[u][0];
+                const long a1 = (static_cast<long>(ab[u][3]) << 32) | ab[u][2];
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    const int row = 16 * j + r, ch = u * 4 + q;
+                    const uint4_t bv = *reinterpret_cast<const uint4_t *>(&xs[buf][row * RB + ((ch ^ (row & 15)) << 4)]);
+                    const long b0 = (static_cast<long>(bv[1]) << 32) | bv[0];
+                    const long b1 = (static_cast<long>(bv[3]) << 32) | bv[2];
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a0, b0, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a1, b1, acc[j], 0, 0, 0);
                 }
             } else {
                 const half8_t a0 = dequant_i8x8(ab[u][0], ab[u][1]), a1 = dequant_i8x8(ab[u][2], ab[u][3]);
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {
                     const int row = 16 * j + r, ch = u * 8 + 2 * q;  // 16 consecutive k of this lane = chunks ch, ch+1
-                    const half8_t b0 = *reinterpret_cast<const half8_t *>(&xs[buf][row * BK + ((ch ^ (row & 15)) << 3)]);
-                    const half8_t b1 = *reinterpret_cast<const half8_t *>(&xs[buf][row * BK + (((ch + 1) ^ (row & 15)) << 3)]);
+                    const half8_t b0 = *reinterpret_cast<const half8_t *>(&xs[buf][row * RB + ((ch ^ (row & 15)) << 4)]);
+                    const half8_t b1 = *reinterpret_cast<const half8_t *>(&xs[buf][row * RB + (((ch + 1) ^ (row & 15)) << 4)]);
                     acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, acc[j], 0, 0, 0);
                     acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, acc[j], 0, 0, 0);
                 }
@@ -740,9 +813,9 @@ __global__ __launch_bounds__(256) void skinny_splitk_kernel(const half_t *__rest
     }
 }
 
-// y = sum over the KS slabs (* per-row scale for int8) (+bias)(+residual) | SwiGLU over (n, N/2+n)
+// y = sum over the KS slabs (* scales of the weight format) (+bias)(+residual) | SwiGLU over (n, N/2+n)
 static __global__ __launch_bounds__(256) void skinny_finalize_kernel(const float *__restrict__ slab, half_t *y, int M, int N, int KS,
-                                                              const half_t *__restrict__ scale, const half_t *__restrict__ bias,
+                                                              const SlabScale scale, const half_t *__restrict__ bias,
                                                               const half_t *residual, int epi) {
     const int out_n = epi == EPI_SWIGLU ? N / 2 : N;
     const size_t total = static_cast<size_t>(M) * out_n;
@@ -752,7 +825,7 @@ static __global__ __launch_bounds__(256) void skinny_finalize_kernel(const float
         auto gather = [&](int col) {
             float v = 0.f;
             for (int k = 0; k < KS; ++k) v += slab[k * slab_sz + static_cast<size_t>(m) * N + col];
-            return scale ? v * to_f32(scale[col]) : v;
+            return scale.apply(v, m, col);
         };
         float v;
         if (epi == EPI_SWIGLU) {

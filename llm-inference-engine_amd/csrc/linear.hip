@@ -20,37 +20,37 @@ static int decode_gemm_mode() {
 // ---- decode GEMV dispatch ----
 // K-split kernel: XC = 16-byte chunks per thread = ceil(K*WBITS/128/256) rounded up to {1,2,3,4,6,8}; RPW rows per
 // iteration so that RPW*XC ~ 16 loads are in flight per lane; register budget M*XC*XE <= 16 half8 of activations.
-template <int M, int RPW, int XC, int WBITS, bool DB = false> static void launch_ksplit(const GemvArgs &a, hipStream_t st) {
+template <int M, int RPW, int XC, int WBITS, bool DB = false, bool FP8 = false> static void launch_ksplit(const GemvArgs &a, hipStream_t st) {
     const bool swiglu = a.epi == EPI_SWIGLU;
     const int groups = swiglu ? (a.N / 2 + RPW / 2 - 1) / (RPW / 2) : (a.N + RPW - 1) / RPW;
     // long-lived workgroups (the prologue -- activation slice + norm -- is paid once per workgroup), evenly loaded
     static const int target = env_int("LLMIE_GEMV_TARGET_WGS", 768);
     const int iters = (groups + target - 1) / target;
     const int grid = (groups + iters - 1) / iters;
-    gemv_ksplit_kernel<M, RPW, XC, WBITS, DB><<<grid, 256, 0, st>>>(a);
+    gemv_ksplit_kernel<M, RPW, XC, WBITS, DB, FP8><<<grid, 256, 0, st>>>(a);
 }
 
 static int ksplit_xc(int K, int wbits) { return (K * wbits / 128 + 255) / 256; }
 
-template <int M, int WBITS> static bool dispatch_ksplit(const GemvArgs &a, hipStream_t st) {
+template <int M, int WBITS, bool FP8 = false> static bool dispatch_ksplit(const GemvArgs &a, hipStream_t st) {
     constexpr int XE = WFmt<WBITS>::XE;
     const int xc = ksplit_xc(a.K, WBITS);
     if constexpr (M * 1 * XE <= 16) {
         if (xc <= 1) {  // quantised rows are short: 8 rows per group, double buffered (16 loads in flight per lane)
             if constexpr (WBITS == 16) launch_ksplit<M, 8, 1, 16>(a, st);
-            else launch_ksplit<M, 8, 1, WBITS, true>(a, st);
+            else launch_ksplit<M, 8, 1, WBITS, true, FP8>(a, st);
             return true;
         }
     }
     if constexpr (M * 2 * XE <= 16) {
         if (xc <= 2) {
             if constexpr (WBITS == 16) launch_ksplit<M, 8, 2, 16>(a, st);
-            else launch_ksplit<M, 4, 2, WBITS, true>(a, st);
+            else launch_ksplit<M, 4, 2, WBITS, true, FP8>(a, st);
             return true;
         }
     }
     if constexpr (M * 3 * XE <= 16 && WBITS != 16) {
-        if (xc <= 3) { launch_ksplit<M, 2, 3, WBITS, true>(a, st); return true; }
+        if (xc <= 3) { launch_ksplit<M, 2, 3, WBITS, true, FP8>(a, st); return true; }
     }
     if constexpr (M * 4 * XE <= 16 && WBITS == 16) {
         if (xc <= 4) { launch_ksplit<M, 4, 4, WBITS>(a, st); return true; }
@@ -118,6 +118,20 @@ template <int WBITS> static bool dispatch_gemv_q(int M, const GemvArgs &a, hipSt
 bool gemv_q_launch(int wbits, int M, const GemvArgs &a, hipStream_t st) {
     return wbits == 8 ? dispatch_gemv_q<8>(M, a, st) : dispatch_gemv_q<4>(M, a, st);
 }
+// fp8 (e4m3 weights, fp32 row scales in a.scale, activations quantised per token in the prologue)
+bool gemv_fp8_launch(int M, const GemvArgs &a, hipStream_t st) {
+    switch (M) {
+        case 1: return dispatch_ksplit<1, 8, true>(a, st);
+        case 2: return dispatch_ksplit<2, 8, true>(a, st);
+        case 3: return dispatch_ksplit<3, 8, true>(a, st);
+        case 4: return dispatch_ksplit<4, 8, true>(a, st);
+        case 5: return dispatch_ksplit<5, 8, true>(a, st);
+        case 6: return dispatch_ksplit<6, 8, true>(a, st);
+        case 7: return dispatch_ksplit<7, 8, true>(a, st);
+        case 8: return dispatch_ksplit<8, 8, true>(a, st);
+        default: return false;
+    }
+}
 
 template <int EPI>
 static bool dispatch_skinny(int M, const half_t *x, const half_t *W, half_t *y, int K, int N,
@@ -176,9 +190,11 @@ static float *splitk_scratch(size_t floats) {
 // split-K skinny MFMA path, first half: partial products of one pass (8 < M <= 128) into the library's fp32 slabs
 // [KS][M][N].  The slabs stay valid until the next split-K launch on the stream; the consumer (finalize kernel,
 // splitk_rownorm, or the decode attention reading q/k/v straight from the slabs) must be enqueued before it.
-int linear_splitk_partial(int wbits, const half_t *x, const void *W, int M, int K, int N, hipStream_t st, SplitKSlabs *out) {
+int linear_splitk_partial(int wbits, const void *x, const void *W, int M, int K, int N, hipStream_t st, SplitKSlabs *out) {
+    // wbits: 16 = fp16 weights, 8 = int8 weights (both with fp16 activations), WF_FP8 = e4m3 weights and e4m3 activations
     const int bk = wbits == 16 ? 128 : 256;  // k per sub-block (4 weight loads per lane)
-    if (M < 1 || M > 128 || K % bk || K < 512 || (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) % 16) {
+    if (M < 1 || M > 128 || K % bk || K < 512 || (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) % 16 ||
+        (wbits != 16 && wbits != 8 && wbits != WF_FP8)) {
         set_error("linear(split-K): unsupported shape M=%d K=%d (bits=%d)", M, K, wbits);
         return LLMIE_ERR_UNSUPPORTED;
     }
@@ -198,7 +214,8 @@ int linear_splitk_partial(int wbits, const half_t *x, const void *W, int M, int 
     const dim3 grid(tiles * KS);
 #define LLMIE_SK(MT_)                                                                                          \
     (wbits == 16 ? skinny_splitk_kernel<MT_, 16><<<grid, 256, 0, st>>>(x, W, slab, M, K, N, KS, spp)              \
-                 : skinny_splitk_kernel<MT_, 8><<<grid, 256, 0, st>>>(x, W, slab, M, K, N, KS, spp))
+     : wbits == 8 ? skinny_splitk_kernel<MT_, 8><<<grid, 256, 0, st>>>(x, W, slab, M, K, N, KS, spp)              \
+                  : skinny_splitk_kernel<MT_, 8, true><<<grid, 256, 0, st>>>(x, W, slab, M, K, N, KS, spp))
     switch (mt) {
         case 1: LLMIE_SK(1); break;
         case 2: LLMIE_SK(2); break;
@@ -230,10 +247,22 @@ int linear_splitk(int wbits, const half_t *x, const void *W, const half_t *scale
         const size_t total = static_cast<size_t>(mc) * out_n;
         int fgrid = static_cast<int>((total + 255) / 256);
         if (fgrid > 2048) fgrid = 2048;
-        skinny_finalize_kernel<<<fgrid, 256, 0, st>>>(sk.slab, y + static_cast<size_t>(m0) * out_n, mc, N, sk.KS, scale, bias,
+        skinny_finalize_kernel<<<fgrid, 256, 0, st>>>(sk.slab, y + static_cast<size_t>(m0) * out_n, mc, N, sk.KS,
+                                                      SlabScale{scale, nullptr, nullptr}, bias,
                                                       residual ? residual + static_cast<size_t>(m0) * N : nullptr, epi);
     }
     return launch_status("linear(split-K)");
+}
+
+// elementwise consumer of the slabs: y = scale(sum_ks slab) (+bias) (+residual) | SwiGLU over (n, N/2 + n)
+int splitk_finalize(const SplitKSlabs &sk, const SlabScale &sc, half_t *y, int epi, const half_t *bias, const half_t *residual,
+                    hipStream_t st) {
+    const int out_n = epi == EPI_SWIGLU ? sk.N / 2 : sk.N;
+    const size_t total = static_cast<size_t>(sk.M) * out_n;
+    int fgrid = static_cast<int>((total + 255) / 256);
+    if (fgrid > 2048) fgrid = 2048;
+    skinny_finalize_kernel<<<fgrid, 256, 0, st>>>(sk.slab, y, sk.M, sk.N, sk.KS, sc, bias, residual, epi);
+    return launch_status("linear(split-K finalize)");
 }
 
 // Row epilogue of a split-K projection fused with the residual stream and the next RMSNorm (one launch instead of
@@ -242,10 +271,13 @@ int linear_splitk(int wbits, const half_t *x, const void *W, const half_t *scale
 //   y[m][:] = gamma ? t * rsqrt(mean(t^2) + eps) * gamma : t
 // One 1024-thread workgroup per row (a thread owns 4 columns per 4096; every slab load of the row is in flight at
 // once: the slabs were just written by other XCDs, so each load is a full memory round trip).  N <= 8192, N % 4 == 0.
+// With xq != null the normalised row is ALSO quantised per token to e4m3 (scale amax/448 -> xscale[m]; the arithmetic of
+// quantize_rows_fp8_kernel on the fp16-rounded values), the input format of the next fp8 projection.
 static __global__ __launch_bounds__(1024) void splitk_rownorm_kernel(const float *__restrict__ slab, int KS, int M, int N,
-                                                                     const half_t *__restrict__ wscale,
+                                                                     const SlabScale wscale,
                                                                      const half_t *__restrict__ bias, half_t *resid,
-                                                                     const half_t *__restrict__ gamma, float eps, half_t *y) {
+                                                                     const half_t *__restrict__ gamma, float eps, half_t *y,
+                                                                     uint8_t *xq, float *xscale) {
     __shared__ float red[16];
     const int m = blockIdx.x, tid = threadIdx.x;
     const size_t slab_sz = static_cast<size_t>(M) * N;
@@ -283,8 +315,7 @@ static __global__ __launch_bounds__(1024) void splitk_rownorm_kernel(const float
             half4_t o4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float t = v[i][e];
-                if (wscale) t *= to_f32(wscale[c + e]);
+                float t = wscale.apply(v[i][e], m, c + e);
                 // same roundings as the unfused sequence: projection output -> fp16, residual sum -> fp16
                 t = to_f32(from_f32<half_t>(t)) + to_f32(r4[i][e]);
                 o4[e] = from_f32<half_t>(t);
@@ -298,27 +329,41 @@ static __global__ __launch_bounds__(1024) void splitk_rownorm_kernel(const float
     }
     float inv = 1.f;
     if (gamma) inv = rsqrtf(block_sum<16>(ss, red) / static_cast<float>(N) + eps);
+    half4_t o4[NC];
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         if (col[i] < N) {
             const int c = col[i];
-            half4_t o4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o4[e] = from_f32<half_t>(gamma ? v[i][e] * inv * to_f32(gamma[c + e]) : v[i][e]);
-            *reinterpret_cast<half4_t *>(y + static_cast<size_t>(m) * N + c) = o4;
+            for (int e = 0; e < 4; ++e) {
+                o4[i][e] = from_f32<half_t>(gamma ? v[i][e] * inv * to_f32(gamma[c + e]) : v[i][e]);
+                amax = fmaxf(amax, fabsf(to_f32(o4[i][e])));
+            }
+            if (y) *reinterpret_cast<half4_t *>(y + static_cast<size_t>(m) * N + c) = o4[i];
         }
+    }
+    if (xq) {
+        amax = block_max<16>(amax, red);
+        const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+        if (tid == 0) xscale[m] = sc;
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+            if (col[i] < N)
+                *reinterpret_cast<unsigned int *>(xq + static_cast<size_t>(m) * N + col[i]) =
+                    pack4_e4m3(to_f32(o4[i][0]) / sc, to_f32(o4[i][1]) / sc, to_f32(o4[i][2]) / sc, to_f32(o4[i][3]) / sc);
     }
 }
 
 bool splitk_rownorm_eligible(int N) { return N % 4 == 0 && N <= 8192; }
 
-int splitk_rownorm(const SplitKSlabs &sk, const half_t *wscale, const half_t *bias, half_t *resid, const half_t *gamma,
-                   float eps, half_t *y, hipStream_t st) {
+int splitk_rownorm(const SplitKSlabs &sk, const SlabScale &wscale, const half_t *bias, half_t *resid, const half_t *gamma,
+                   float eps, half_t *y, uint8_t *xq, float *xscale, hipStream_t st) {
     if (!splitk_rownorm_eligible(sk.N)) {
         set_error("splitk_rownorm: N=%d not supported", sk.N);
         return LLMIE_ERR_UNSUPPORTED;
     }
-    splitk_rownorm_kernel<<<sk.M, 1024, 0, st>>>(sk.slab, sk.KS, sk.M, sk.N, wscale, bias, resid, gamma, eps, y);
+    splitk_rownorm_kernel<<<sk.M, 1024, 0, st>>>(sk.slab, sk.KS, sk.M, sk.N, wscale, bias, resid, gamma, eps, y, xq, xscale);
     return launch_status("splitk_rownorm");
 }
 

@@ -22,16 +22,27 @@ struct SplitKSlabs {
     float *slab;
     int KS, M, N;
 };
-int linear_splitk_partial(int wbits, const half_t *x, const void *W, int M, int K, int N, hipStream_t st, SplitKSlabs *out);
+enum : int { WF_FP8 = 108 };  // wbits code of e4m3 weights + e4m3 activations (16 / 8 = fp16 / int8 weights, fp16 activations)
+int linear_splitk_partial(int wbits, const void *x, const void *W, int M, int K, int N, hipStream_t st, SplitKSlabs *out);
+int splitk_finalize(const SplitKSlabs &sk, const SlabScale &sc, half_t *y, int epi, const half_t *bias, const half_t *residual,
+                    hipStream_t st);
 bool splitk_rownorm_eligible(int N);
-int splitk_rownorm(const SplitKSlabs &sk, const half_t *wscale, const half_t *bias, half_t *resid, const half_t *gamma,
-                   float eps, half_t *y, hipStream_t st);
+// y (fp16, may be null) and/or xq + xscale (per-token e4m3, may be null) receive the normalised row
+int splitk_rownorm(const SplitKSlabs &sk, const SlabScale &wscale, const half_t *bias, half_t *resid, const half_t *gamma,
+                   float eps, half_t *y, uint8_t *xq, float *xscale, hipStream_t st);
+// per-token e4m3 quantisation of fp16 rows (scale amax/448); fp8_linear.hip
+int quantize_rows_fp8(const half_t *x, uint8_t *xq, float *xscale, int M, int K, hipStream_t st);
 int linear_splitk(int wbits, const half_t *x, const void *W, const half_t *scale, half_t *y, int M, int K, int N, int epi,
                   const half_t *bias, const half_t *residual, hipStream_t st);
 // quantised-weight (int8 / int4) decode GEMV on the K-split kernel; defined in linear.hip
 struct GemvArgs;
 bool ksplit_eligible(int M, int K, int wbits);
 bool gemv_q_launch(int wbits, int M, const GemvArgs &a, hipStream_t st);
+bool gemv_fp8_launch(int M, const GemvArgs &a, hipStream_t st);
+// fp8 linear on the GEMV path (M <= 8, ksplit_eligible(M, K, 8)); optional fused norm prologue / SwiGLU epilogue; fp8_linear.hip
+int linear_fp8_gemv(const half_t *x, const uint8_t *wq, const float *wscale, half_t *y, int M, int K, int N, int epi,
+                    const half_t *bias, const half_t *residual, const half_t *gamma, const half_t *pre_bias, float eps,
+                    hipStream_t st);
 // weight-only int8/int4 linear with optional fused norm prologue / SwiGLU epilogue (quant_linear.hip)
 int linear_wq(int wbits, const half_t *x, const void *wq, const half_t *scale, half_t *y, int M, int K, int N, int group,
               int epi, const half_t *bias, const half_t *residual, const half_t *gamma, const half_t *pre_bias, float eps,
@@ -44,7 +55,7 @@ int decoder_mha_rope(const void *qkv, const void *qkv_bias, void *k_cache, void 
                      int32_t *tickets /* [batch,kvh] zeroed arrival counters: in-launch merge; null = merge kernel */,
                      llmie_dtype dtype, hipStream_t st,
                      const SplitKSlabs *qkv_slabs = nullptr /* q/k/v read from the QKV projection's split-K slabs (qkv unused) */,
-                     const half_t *qkv_wscale = nullptr);
+                     const SlabScale *qkv_scale = nullptr);
 
 // prefill attention (RoPE + KV append + flash attention) on the packed QKV buffer; prefill.hip
 int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, half_t *k_cache, half_t *v_cache, half_t *out,

@@ -210,6 +210,60 @@ def test_linear_fp8(llmie, M, K, N):
     assert np.abs(y.float().cpu().numpy() - ref).max() <= 0.12 * np.abs(ref).max()
 
 
+def _fp8_lin(x, wdeq):
+    """fp8 projection as the engine defines it: per-token e4m3 activations (scale amax/448) x de-quantised e4m3 weights"""
+    xs = (np.abs(x).max(axis=1) / np.float32(448.0)).astype(np.float32)
+    xs[xs == 0] = 1.0
+    _, xdeq = _to_e4m3(x / xs[:, None])
+    return orc.linear(xdeq * xs[:, None], wdeq)
+
+
+@pytest.mark.parametrize("bs", [1, 4, 20, 72])
+def test_fp8_decoder_matches_oracle_composition(llmie, bs):
+    """one 7B-geometry layer, fp8 weights + per-token fp8 activations, against the oracle's kernels composed in numpy
+    with the activation quantisation emulated (batch 1/4: GEMV path, 20/72: MFMA path)"""
+    rng = np.random.default_rng(54)
+    nh, hs, I, L, max_seq, step = 32, 128, 11008, 1, 64, 33
+    H, QKV = nh * hs, 3 * nh * hs
+    tab = _e4m3_table()
+    mats, deq = {}, {}
+    for k, (n, kk) in dict(qkv=(QKV, H), o=(H, H), gate_up=(2 * I, H), down=(H, I)).items():
+        w = torch.from_numpy(_h(rng.uniform(-1, 1, (n, kk)).astype(np.float32) * 2 / np.sqrt(kk))).to(DEV).to(F16)
+        q = torch.empty((n, kk), dtype=torch.uint8, device=DEV)
+        sc = torch.empty(n, dtype=torch.float32, device=DEV)
+        llmie.quantize_fp8(w, q, sc)
+        mats[k] = dict(data=q, scale=sc)
+        deq[k] = tab[q.cpu().numpy()] * sc.cpu().numpy()[:, None]
+    g1, g2 = _h(rng.uniform(0.8, 1.2, H).astype(np.float32)), _h(rng.uniform(0.8, 1.2, H).astype(np.float32))
+    cfg = dict(head_num=nh, kv_head_num=nh, head_size=hs, inter_size=I, num_layers=L, vocab_size=100, max_seq_len=max_seq,
+               max_batch=bs, rotary_dim=hs, rotary_base=10000.0, rms_eps=1e-5, dtype=llmie.F16, wfmt=llmie.W_FP8, int4_group=128)
+    dec = llmie.Decoder(cfg, [dict(attn_norm=torch.from_numpy(g1).to(DEV).to(F16), ffn_norm=torch.from_numpy(g2).to(DEV).to(F16), **mats)])
+    x = _h(rng.standard_normal((bs, H)).astype(np.float32))
+    kc = _h(rng.standard_normal((L, bs, nh, max_seq, hs)).astype(np.float32) * 0.5)
+    vc = _h(rng.standard_normal((L, bs, nh, max_seq, hs)).astype(np.float32) * 0.5)
+    xd = torch.from_numpy(x).to(DEV).to(F16)
+    out = dec.forward(xd, torch.empty_like(xd), torch.from_numpy(kc).to(DEV).to(F16), torch.from_numpy(vc).to(DEV).to(F16), step)
+    # oracle composition (self_decoder.cpp:69-119 order), fp16 roundings where the engine stores fp16
+    h = _h(orc.rmsnorm(x, g1, 1e-5)[0])
+    qkv = _h(_fp8_lin(h, deq["qkv"]))
+    qkv = _h(orc.rope_decode(qkv, nh, nh, hs, step, hs, 10000.0))
+    mha = _h(orc.decoder_mha(qkv, None, kc, vc, 0, nh, nh, hs, step))
+    h1 = _h(_h(_fp8_lin(mha.reshape(bs, H), deq["o"])) + x)
+    h2 = _h(orc.rmsnorm(h1, g2, 1e-5)[0])
+    gu = _fp8_lin(h2, deq["gate_up"])
+    act = _h(orc.silu_and_mul(gu.reshape(bs, 2, I)))
+    exp = _h(_fp8_lin(act.reshape(bs, I), deq["down"])) + h1
+    got = out.float().cpu().numpy()
+    # Per-token dynamic fp8 is chaotic at the element level: an fp16-ulp difference in an activation row (summation
+    # order) moves some elements across an e4m3 rounding boundary (a 6% step), and two quantisation stages amplify
+    # that to ~2% of the output scale.  The projections themselves are pinned to 3e-3 by test_linear_fp8 on identical
+    # inputs; the layer is held to 3% in the Frobenius norm (the fp16 layer it approximates is ~8% away).
+    rel = np.linalg.norm(got - exp) / np.linalg.norm(exp)
+    assert rel < 0.03, rel
+    assert np.abs(got - exp).max() <= 0.3
+    dec.close()
+
+
 def test_fp8_decoder_runs_and_tracks_fp16(llmie):
     rng = np.random.default_rng(53)
     nh, hs, I, L, max_seq, step, bs = 32, 128, 11008, 1, 64, 20, 4

@@ -23,7 +23,7 @@ step_dev = torch.tensor([S - P], dtype=torch.int32, device="cuda")
 for _ in range(2):
     dec.forward(hidden, out, kc, vc, -1, step_dev=step_dev)
 torch.cuda.synchronize()
-dec.profile_begin(P * (cfg["num_layers"] * 8 + 4))
+dec.profile_begin(P * (cfg["num_layers"] * 12 + 8))
 for _ in range(P):
     dec.forward(hidden, out, kc, vc, -1, step_dev=step_dev)
     llmie.advance_step(step_dev)
