@@ -462,7 +462,7 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
     return LLMIE_OK;
 }
 
-static size_t prefill_carve(const llmie_decoder_config *c, int T, int B, size_t *o /*[7]*/) {
+static size_t prefill_carve(const llmie_decoder_config *c, int T, int B, size_t *o /*[8]*/) {
     const size_t e = 2, H = static_cast<size_t>(c->head_num) * c->head_size;
     const size_t QKV = static_cast<size_t>(c->head_num + 2 * c->kv_head_num) * c->head_size, I = c->inter_size;
     Carve k;
@@ -473,12 +473,14 @@ static size_t prefill_carve(const llmie_decoder_config *c, int T, int B, size_t 
     o[4] = k.take(static_cast<size_t>(T) * I * e);        // act
     o[5] = k.take(static_cast<size_t>(T) * sizeof(int32_t));        // padding offsets (by-product of the prefix kernel)
     o[6] = k.take(static_cast<size_t>(B + 1) * sizeof(int32_t));    // cum_seqlens
+    // fp8 engines: per-token e4m3 image + scales of the activation matrix entering each projection
+    o[7] = k.take(c->wfmt == LLMIE_W_FP8 ? llmie_linear_fp8_workspace_bytes(T, static_cast<int>(I > H ? I : H)) : 256);
     return k.off;
 }
 
 extern "C" size_t llmie_decoder_prefill_workspace_bytes(const llmie_decoder_config *cfg, int max_tokens, int max_batch) {
     if (!config_ok(cfg) || max_tokens <= 0 || max_batch <= 0) return 0;
-    size_t o[7];
+    size_t o[8];
     return prefill_carve(cfg, max_tokens, max_batch, o);
 }
 
@@ -492,9 +494,10 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
     LLMIE_REQUIRE(batch >= 1 && num_tokens >= 1 && max_q_len >= 1 && max_q_len <= num_tokens && max_q_len <= c.max_seq_len,
                   "decoder_prefill: bad shape batch=%d tokens=%d max_q_len=%d", batch, num_tokens, max_q_len);
     LLMIE_REQUIRE(num_tokens <= static_cast<long long>(batch) * max_q_len, "decoder_prefill: num_tokens > batch*max_q_len");
-    if (c.dtype != LLMIE_F16 || c.wfmt != LLMIE_W_F16 || c.head_size != 128)
-        LLMIE_UNSUPPORTED("decoder_prefill: fp16 activations + fp16 weights + head_size 128 only (use the per-kernel path)");
-    size_t o[7];
+    const bool fp8 = c.wfmt == LLMIE_W_FP8;
+    if (c.dtype != LLMIE_F16 || (c.wfmt != LLMIE_W_F16 && !fp8) || c.head_size != 128)
+        LLMIE_UNSUPPORTED("decoder_prefill: fp16 activations + fp16 or fp8 weights + head_size 128 only (use the per-kernel path)");
+    size_t o[8];
     const size_t need = prefill_carve(&c, num_tokens, batch, o);
     if (workspace_bytes < need || reinterpret_cast<uintptr_t>(workspace) % 256) {
         set_error("decoder_prefill: workspace too small or unaligned (%zu < %zu)", workspace_bytes, need);
@@ -514,22 +517,31 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
         }
     }
     half_t *h = (half_t *)hidden_out;
+    void *f8ws = base + o[7];
+    const size_t f8ws_bytes = fp8 ? llmie_linear_fp8_workspace_bytes(T, I > H ? I : H) : 0;
+    // y = x . W^T (+ residual) in the engine's weight format (fp8: per-token e4m3 activations, fp8 MFMA)
+    auto proj = [&](const half_t *x, const llmie_matrix &w, half_t *y, int K, int N, const half_t *residual) -> int {
+        if (fp8)
+            return llmie_linear_fp8(x, (const uint8_t *)w.data, (const float *)w.scale, y, T, K, N, nullptr, residual, f8ws,
+                                    f8ws_bytes, stream);
+        return linear_f16_nk(x, (const half_t *)w.data, y, T, K, N, EPI_NONE_, nullptr, residual, st);
+    };
     // context_decoder.cpp:70: exclusive prefix of the lengths (padding offsets are a by-product nobody needs here);
     // the prefix kernel takes [batch, max_q_len] with max_q_len = ceil(T / batch) rows worth of scratch -> use 1 row of T
     if ((rc = llmie_cal_padding_offset(pad, cum, input_lengths, batch, (T + batch - 1) / batch, stream))) return rc;
     for (int l = 0; l < c.num_layers; ++l) {
         const llmie_layer_weights &w = dec->layers[l];
         TIMED(LLMIE_OP_ATTN_NORM, llmie_rmsnorm(h, resid, w.attn_norm_gamma, c.rms_eps, T, H, LLMIE_F16, stream));
-        TIMED(LLMIE_OP_QKV_GEMM, linear_f16_nk(h, (const half_t *)w.qkv.data, qkv, T, H, QKV, EPI_NONE_, nullptr, nullptr, st));
+        TIMED(LLMIE_OP_QKV_GEMM, proj(h, w.qkv, qkv, H, QKV, nullptr));
         TIMED(LLMIE_OP_MHA, prefill_attention_f16(qkv, (const half_t *)w.qkv.bias, (half_t *)k_cache, (half_t *)v_cache, attn, cum,
                                                   history_lengths, dec->rope_table, l, batch, T, max_q_len, c.head_num,
                                                   c.kv_head_num, c.head_size, c.max_seq_len, c.rotary_dim, st));
-        TIMED(LLMIE_OP_O_GEMM, linear_f16_nk(attn, (const half_t *)w.o.data, h, T, H, H, EPI_NONE_, nullptr, nullptr, st));
+        TIMED(LLMIE_OP_O_GEMM, proj(attn, w.o, h, H, H, nullptr));
         TIMED(LLMIE_OP_FFN_NORM, llmie_fused_add_bias_residual_rmsnorm(resid, h, w.o.bias, w.ffn_norm_gamma, c.rms_eps, T, H,
                                                                        LLMIE_F16, stream));
-        TIMED(LLMIE_OP_GATE_UP_SWIGLU, linear_f16_nk(h, (const half_t *)w.gate_up.data, gu, T, H, 2 * I, EPI_NONE_, nullptr, nullptr, st));
+        TIMED(LLMIE_OP_GATE_UP_SWIGLU, proj(h, w.gate_up, gu, H, 2 * I, nullptr));
         TIMED(LLMIE_OP_GATE_UP_SWIGLU, llmie_silu_and_mul(gu, act, T, I, LLMIE_F16, stream));
-        TIMED(LLMIE_OP_DOWN_GEMM, linear_f16_nk(act, (const half_t *)w.down.data, h, T, I, H, EPI_NONE_, nullptr, resid, st));
+        TIMED(LLMIE_OP_DOWN_GEMM, proj(act, w.down, h, I, H, resid));
     }
     return LLMIE_OK;
 }

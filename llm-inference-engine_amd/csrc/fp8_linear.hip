@@ -79,8 +79,11 @@ extern "C" int llmie_linear_fp8(const void *x, const uint8_t *w_fp8, const float
                                 llmie_stream stream) {
     LLMIE_REQUIRE(x && w_fp8 && w_scale && y && workspace, "linear_fp8: NULL pointer");
     LLMIE_REQUIRE(M > 0 && K > 0 && N > 0, "linear_fp8: bad shape");
-    if (K % 256 != 0 || K < 512 || reinterpret_cast<uintptr_t>(w_fp8) % 16 || reinterpret_cast<uintptr_t>(workspace) % 256)
-        LLMIE_UNSUPPORTED("linear_fp8: needs K %% 256 == 0, K >= 512, 16-byte aligned weights, 256-byte aligned workspace");
+    const bool tiled = M > 8 && gemm256_fills(M, N) && K % 128 == 0 && N % 4 == 0 && reinterpret_cast<uintptr_t>(w_scale) % 16 == 0 &&
+                       (reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) % 8 == 0;
+    if ((!tiled && (K % 256 != 0 || K < 512)) || reinterpret_cast<uintptr_t>(w_fp8) % 16 || reinterpret_cast<uintptr_t>(workspace) % 256)
+        LLMIE_UNSUPPORTED("linear_fp8: needs K %% 256 == 0, K >= 512 (K %% 128 == 0 for prefill-sized M x N), 16-byte aligned "
+                          "weights, 256-byte aligned workspace");
     if (workspace_bytes < llmie_linear_fp8_workspace_bytes(M, K)) {
         set_error("linear_fp8: workspace too small");
         return LLMIE_ERR_WORKSPACE;
@@ -94,6 +97,11 @@ extern "C" int llmie_linear_fp8(const void *x, const uint8_t *w_fp8, const float
     float *xscale = reinterpret_cast<float *>(xq + fp8_align(static_cast<size_t>(M) * K));
     int rc = quantize_rows_fp8((const half_t *)x, xq, xscale, M, K, st);
     if (rc) return rc;
+    if (tiled) {
+        // prefill-sized: MFMA-bound tiled GEMM on v_mfma_scale_f32_16x16x128_f8f6f4
+        gemm256_launch(true, xq, w_fp8, (half_t *)y, M, N, K, (const half_t *)bias, (const half_t *)residual, xscale, w_scale, st);
+        return launch_status("linear_fp8(gemm256)");
+    }
     for (int m0 = 0; m0 < M; m0 += 128) {
         const int mc = M - m0 < 128 ? M - m0 : 128;
         SplitKSlabs sk;

@@ -1,0 +1,185 @@
+// 256 x 256 x 64 MFMA GEMM for prefill-sized projections (gfx950):  C[M,N] = X[M,K] . W[N,K]^T (+bias)(+residual), fp16 in,
+// fp32 accumulate -- the linear of launchLinearGemm (linear.cu:10-87) at M >= a few hundred tokens, where the op is
+// MFMA-bound instead of weight-bandwidth-bound.
+//
+// Why a second tiled kernel: the 128 x 128 kernel in gemm_kernels.cuh stages global -> VGPR -> LDS (ds_write_b128 costs 13
+// LDS-path cycles per wave instruction) and gives each wave a 64 x 64 tile, i.e. 8 fragment reads per 16 MFMAs; its
+// LDS traffic is longer than its MFMA time and it tops out at ~0.9 PFLOP/s (35% of the dense fp16 peak).  Here
+//   * both operand tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write), double buffered:
+//     the DMA of k-tile t+1 runs under the MFMAs of k-tile t, one barrier per k-tile;
+//   * 8 waves (2 x 4) per workgroup, each wave owns 128 x 64 of C = 8 x 4 MFMA tiles (128 accumulator registers) and
+//     reads 12 fragments per 32 MFMAs;
+//   * an LDS-DMA wave instruction writes 1 KiB linearly (wave-uniform base + lane * 16 B), so the XOR swizzle that makes the
+//     fragment reads conflict-free is applied on the SOURCE address: LDS slot (row, s) receives chunk s ^ (row & 7).
+// LDS image per stage: X half 0 | X half 1 | W half 0 | W half 1, each 128 rows x 128 B (64 k) = 16 KiB; 2 stages = 128 KiB.
+#pragma once
+#include "device_utils.cuh"
+
+namespace llmie {
+
+// FP8 form: X and W are e4m3 bytes (X quantised per token, W per output row), a k-tile is 128 k = the same 128-byte rows,
+// one v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales, E8M0 127) per output tile and k-tile -- twice the fp16 MFMA
+// rate -- and the epilogue applies xscale[m] * wscale[n].
+typedef int intx8 __attribute__((ext_vector_type(8)));
+
+// WN = MFMA column tiles per wave: 4 -> 256 x 256 workgroup tile, 2 -> 256 x 128 (one W half per stage, 96 KiB of LDS) for
+// projections whose 256-wide grid would leave CUs idle (N = 4096 at 2048 tokens: 128 vs 256 workgroups).
+template <bool FP8, bool HAS_EPI, int WN = 4>
+__global__ __launch_bounds__(512) void gemm256_kernel(const void *__restrict__ Xv, const void *__restrict__ Wv, half_t *C,
+                                                      int M, int N, int K, const half_t *__restrict__ bias,
+                                                      const half_t *residual, int tiles_n, const float *__restrict__ xscale,
+                                                      const float *__restrict__ wscale) {
+    constexpr int ES = FP8 ? 1 : 2;            // bytes per element
+    constexpr int BK = 128 / ES;               // k per tile: rows of 128 bytes either way
+    constexpr int BN = 64 * WN;                // workgroup tile columns
+    constexpr int NHALF = 2 + BN / 128;        // 128-row half tiles per stage: X0 X1 W0 [W1]
+    constexpr int HALF_BYTES = 128 * 128, STAGE_BYTES = NHALF * HALF_BYTES;
+    const unsigned char *X = static_cast<const unsigned char *>(Xv), *W = static_cast<const unsigned char *>(Wv);
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];  // [2][4][128 * 128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;  // wave grid 2 (M) x 4 (N)
+    const int r = lane & 15, q = lane >> 4;
+    // consecutive workgroups walk down M inside one 256-wide column of W: the W tile is shared through L2 by the
+    // workgroups that are resident together, X (the smaller operand at prefill) is re-read per column
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * 256, n0 = tile_n * BN;
+
+    // ---- LDS-DMA plan: half-tile h (0,1 = X rows m0 + 128 h ..; 2,3 = W rows n0 + 128 (h-2) ..), instruction i (0,1):
+    //      this wave fills rows (i*8 + wave)*8 .. +8 of the half; lane -> row + lane/8, slot lane%8 <- chunk slot ^ (row & 7)
+    const unsigned char *src[NHALF][2];
+#pragma unroll
+    for (int h = 0; h < NHALF; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (i * 8 + wave) * 8 + (lane >> 3), slot = lane & 7, chunk = slot ^ (row & 7);
+            const int grow = h < 2 ? min(m0 + h * 128 + row, M - 1) : min(n0 + (h - 2) * 128 + row, N - 1);  // clamped: never stored
+            src[h][i] = (h < 2 ? X : W) + static_cast<size_t>(grow) * K * ES + chunk * 16;
+        }
+    auto dma_tile = [&](int kt, int stage) {
+#pragma unroll
+        for (int h = 0; h < NHALF; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                unsigned char *dst = lds + stage * STAGE_BYTES + h * HALF_BYTES + (i * 8 + wave) * 1024;  // wave-uniform
+                typedef const __attribute__((address_space(1))) void *gptr_t;
+                typedef __attribute__((address_space(3))) void *lptr_t;
+                __builtin_amdgcn_global_load_lds((gptr_t)(src[h][i] + static_cast<size_t>(kt) * 128), (lptr_t)dst, 16, 0, 0);
+            }
+    };
+
+    floatx4 acc[8][WN];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment addresses inside a stage: X row-tile i of this wave -> half wr, row i*16 + r; W col-tile j -> half 2 + (wc >> 1),
+    // row (wc & 1) * 64 + j*16 + r; chunk c = ks*4 + q sits in slot c ^ (row & 7)
+    const int wcol = wc * 16 * WN;  // first column of this wave inside the workgroup tile
+    const int a_row0 = r, b_row0 = (wcol & 127) + r;
+    const unsigned char *a_base = lds + wr * HALF_BYTES, *b_base = lds + (2 + (wcol >> 7)) * HALF_BYTES;
+    auto frag = [&](const unsigned char *base, int row, int c) {
+        return *reinterpret_cast<const half8_t *>(base + row * 128 + ((c ^ (row & 7)) << 4));
+    };
+
+    const int KT = K / BK;
+    dma_tile(0, 0);
+    __syncthreads();  // drains the DMA (vmcnt(0)) and publishes stage 0
+    for (int kt = 0; kt < KT; ++kt) {
+        const int stage = kt & 1;
+        if (kt + 1 < KT) dma_tile(kt + 1, stage ^ 1);  // lands while this k-tile is multiplied
+        const unsigned char *ab = a_base + stage * STAGE_BYTES, *bb = b_base + stage * STAGE_BYTES;
+        if constexpr (FP8) {
+            // lane (r, q) supplies k bytes [32q, 32q + 32) of its row: slots 2q and 2q + 1 (any lane -> k assignment is
+            // fine as long as both operands use the same one)
+            auto frag8 = [&](const unsigned char *base, int row) {
+                const uint4_t lo = *reinterpret_cast<const uint4_t *>(base + row * 128 + (((2 * q) ^ (row & 7)) << 4));
+                const uint4_t hi = *reinterpret_cast<const uint4_t *>(base + row * 128 + (((2 * q + 1) ^ (row & 7)) << 4));
+                return intx8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+            };
+            intx8 bf[WN];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bf[j] = frag8(bb, b_row0 + j * 16);
+#pragma unroll
+            for (int ih = 0; ih < 2; ++ih) {
+                intx8 af[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = frag8(ab, a_row0 + (ih * 4 + i) * 16);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[ih * 4 + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                            bf[j], af[i], acc[ih * 4 + i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+            }
+        } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8_t bf[WN];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bf[j] = frag(bb, b_row0 + j * 16, ks * 4 + q);
+#pragma unroll
+            for (int ih = 0; ih < 2; ++ih) {
+                half8_t af[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = frag(ab, a_row0 + (ih * 4 + i) * 16, ks * 4 + q);
+                // D[n-row, m-col] convention: W as the MFMA A operand gives 4 consecutive n per lane (8-byte stores)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[ih * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[ih * 4 + i][j], 0, 0, 0);
+            }
+        }
+        }
+        __syncthreads();  // every wave done with this stage; the next stage's DMA has landed (the barrier drains vmcnt)
+    }
+
+    // acc[i][j]: lane holds C[m0 + wr*128 + i*16 + r][n0 + wcol + j*16 + 4q + e]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + r;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int n = n0 + wcol + j * 16 + 4 * q;
+            if (n + 3 < N && (N & 3) == 0) {
+                floatx4 v = acc[i][j];
+                if constexpr (FP8) {
+                    const floatx4 ws = *reinterpret_cast<const floatx4 *>(wscale + n);
+                    const float xsm = xscale[m];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= ws[e] * xsm;
+                }
+                if (HAS_EPI) {
+                    if (bias) {
+                        const half4_t b4 = *reinterpret_cast<const half4_t *>(bias + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += to_f32(b4[e]);
+                    }
+                    if (residual) {
+                        const half4_t r4 = *reinterpret_cast<const half4_t *>(residual + static_cast<size_t>(m) * N + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += to_f32(r4[e]);
+                    }
+                }
+                const half4_t o = {from_f32<half_t>(v[0]), from_f32<half_t>(v[1]), from_f32<half_t>(v[2]), from_f32<half_t>(v[3])};
+                *reinterpret_cast<half4_t *>(C + static_cast<size_t>(m) * N + n) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < N) {
+                        float v = acc[i][j][e];
+                        if constexpr (FP8) v *= wscale[n + e] * xscale[m];
+                        if (HAS_EPI) {
+                            if (bias) v += to_f32(bias[n + e]);
+                            if (residual) v += to_f32(residual[static_cast<size_t>(m) * N + n + e]);
+                        }
+                        C[static_cast<size_t>(m) * N + n + e] = from_f32<half_t>(v);
+                    }
+            }
+        }
+    }
+}
+
+}  // namespace llmie

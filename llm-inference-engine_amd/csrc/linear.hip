@@ -1,5 +1,6 @@
 // llmie_linear / llmie_batched_gemm: shape dispatch over the kernels in gemm_kernels.cuh.
 #include "gemm_kernels.cuh"
+#include "gemm256.cuh"
 #include "llmie_internal.h"
 
 #include <cstdlib>
@@ -387,6 +388,48 @@ int linear_f16_nk_norm(const half_t *x, const half_t *W, half_t *y, int M, int K
     return launch_status("linear(norm-fused)");
 }
 
+// 256 x 256 (or 256 x 128) LDS-DMA GEMM (gemm256.cuh): fp16 operands, or e4m3 operands with per-token / per-row scales.
+// Tile choice by grid fill: 256-wide column tiles when they give >= min_tiles workgroups (one per CU), else 128-wide.
+static int gemm256_wn(int M, int N) {
+    static const int min_tiles = env_int("LLMIE_GEMM256_MIN_TILES", 192);
+    const int tm = (M + 255) / 256;
+    if (tm * ((N + 255) / 256) >= min_tiles) return 4;
+    if (tm * ((N + 127) / 128) >= min_tiles) return 2;
+    return 0;
+}
+bool gemm256_fills(int M, int N) { return gemm256_wn(M, N) != 0; }
+
+template <bool FP8, bool EPI, int WN>
+static void gemm256_launch_t(const void *x, const void *W, half_t *y, int M, int N, int K, const half_t *bias, const half_t *residual,
+                             const float *xscale, const float *wscale, hipStream_t st) {
+    constexpr int lds_bytes = 2 * (2 + WN / 2) * 128 * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm256_kernel<FP8, EPI, WN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        attr_set = true;
+    }
+    const int tm = (M + 255) / 256, tn = (N + 64 * WN - 1) / (64 * WN);
+    gemm256_kernel<FP8, EPI, WN><<<tm * tn, 512, lds_bytes, st>>>(x, W, y, M, N, K, bias, residual, tn, xscale, wscale);
+}
+
+void gemm256_launch(bool fp8, const void *x, const void *W, half_t *y, int M, int N, int K, const half_t *bias,
+                    const half_t *residual, const float *xscale, const float *wscale, hipStream_t st) {
+    const int wn = gemm256_wn(M, N) == 2 ? 2 : 4;
+    const bool epi = bias || residual;
+#define LLMIE_G256(F8_, EPI_)                                                                                          \
+    (wn == 4 ? gemm256_launch_t<F8_, EPI_, 4>(x, W, y, M, N, K, bias, residual, xscale, wscale, st)                    \
+             : gemm256_launch_t<F8_, EPI_, 2>(x, W, y, M, N, K, bias, residual, xscale, wscale, st))
+    if (fp8) {
+        if (epi) LLMIE_G256(true, true);
+        else LLMIE_G256(true, false);
+    } else {
+        if (epi) LLMIE_G256(false, true);
+        else LLMIE_G256(false, false);
+    }
+#undef LLMIE_G256
+}
+
 int linear_f16_nk(const half_t *x, const half_t *W, half_t *y, int M, int K, int N, int epi,
                   const half_t *bias, const half_t *residual, hipStream_t st) {
     const bool aligned = (K % 8 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) % 16 == 0);
@@ -407,6 +450,11 @@ int linear_f16_nk(const half_t *x, const half_t *W, half_t *y, int M, int K, int
         return LLMIE_ERR_UNSUPPORTED;
     }
     if (!done && aligned && K % 64 == 0 && reinterpret_cast<uintptr_t>(y) % 8 == 0) {
+        // 256 x 256 LDS-DMA kernel when its grid fills the chip (one 512-thread workgroup per CU); else 128 x 128 tiles
+        if (gemm256_fills(M, N) && (reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) % 8 == 0) {
+            gemm256_launch(false, x, W, y, M, N, K, bias, residual, nullptr, nullptr, st);
+            return launch_status("linear(gemm256)");
+        }
         dim3 grid((N + 127) / 128, (M + 127) / 128, 1);
         if (bias || residual)
             tiled_mfma_f16_kernel<true><<<grid, 256, 0, st>>>(x, W, y, M, N, K, 0, 0, 0, bias, residual);

@@ -34,6 +34,10 @@ int splitk_rownorm(const SplitKSlabs &sk, const SlabScale &wscale, const half_t 
 int quantize_rows_fp8(const half_t *x, uint8_t *xq, float *xscale, int M, int K, hipStream_t st);
 int linear_splitk(int wbits, const half_t *x, const void *W, const half_t *scale, half_t *y, int M, int K, int N, int epi,
                   const half_t *bias, const half_t *residual, hipStream_t st);
+// 256 x 256 LDS-DMA tiled GEMM (gemm256.cuh; K % 64 == 0 fp16, K % 128 == 0 fp8; 16-byte aligned operands); linear.hip
+bool gemm256_fills(int M, int N);
+void gemm256_launch(bool fp8, const void *x, const void *W, half_t *y, int M, int N, int K, const half_t *bias,
+                    const half_t *residual, const float *xscale, const float *wscale, hipStream_t st);
 // quantised-weight (int8 / int4) decode GEMV on the K-split kernel; defined in linear.hip
 struct GemvArgs;
 bool ksplit_eligible(int M, int K, int wbits);

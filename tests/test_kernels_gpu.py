@@ -218,6 +218,24 @@ def test_linear(llmie, dtype, M, K, N, trans_b):
     close(host(y), exp, *tol(dtype, f32=(1e-4, 2e-5), f16=(2e-3, 2e-3)))
 
 
+@pytest.mark.parametrize("M,K,N,epi", [(4096, 128, 3072, False), (4000, 192, 3100, False), (3900, 256, 3330, True),
+                                       (8192, 64, 2048, True), (4096, 192, 1664, False), (4090, 128, 1602, True)])
+def test_linear_gemm256(llmie, M, K, N, epi):
+    """shapes whose 256 x 256 grid fills the chip (>= 192 tiles) take the LDS-DMA kernel (gemm256.cuh): full tiles,
+    ragged M and N edges, odd k-tile counts, bias + in-place residual epilogue"""
+    rng = np.random.default_rng(M + N)
+    x, w = rnd(rng, (M, K), 1.0, torch.float16), rnd(rng, (N, K), 1.0 / np.sqrt(K), torch.float16)
+    if epi:
+        b, r = rnd(rng, (N,), 1.0, torch.float16), rnd(rng, (M, N), 1.0, torch.float16)
+        y = dev(r, torch.float16)
+        llmie.linear(dev(x, torch.float16), dev(w, torch.float16), y, bias=dev(b, torch.float16), residual=y)
+        close(host(y), orc.linear(x, w) + b[None, :] + r, 2e-3, 4e-3)
+    else:
+        y = torch.full((M, N), 99.0, dtype=torch.float16, device=DEV)
+        llmie.linear(dev(x, torch.float16), dev(w, torch.float16), y)
+        close(host(y), orc.linear(x, w), 2e-3, 2e-3)
+
+
 @pytest.mark.parametrize("M", [1, 4, 20, 150])
 def test_linear_fused_bias_residual(llmie, M):
     rng = np.random.default_rng(9)

@@ -112,3 +112,44 @@ def test_prefill_then_decode_consistency(llmie):
     c, d = part.float().cpu().numpy(), full[100:].float().cpu().numpy()
     assert (np.abs(c - d) <= 2e-2 + 2e-2 * np.abs(d)).all(), np.abs(c - d).max()
     dec.close()
+
+
+def test_fp8_prefill_consistent_with_fp8_decode_and_tracks_fp16(llmie):
+    """fp8 engine (e4m3 weights, per-token e4m3 activations): prefill and decode quantise every token row the same way,
+    so prefill(n+1)[-1] must agree with prefill(n) -> decode(n+1) up to the chaotic rounding noise of dynamic fp8
+    (see test_fp8_decoder_matches_oracle_composition), and the whole prefill stays close to the fp16 engine's."""
+    rng = np.random.default_rng(43)
+    nh, hs, I, L, max_seq, n = 8, 128, 1536, 2, 256, 140
+    H = nh * hs
+    layers = _model(rng, nh, nh, hs, I, L)
+    d16 = _engine(llmie, layers, nh, nh, hs, I, max_seq, 1)
+    eng8 = []
+    for w in layers:
+        lw = dict(attn_norm=torch.from_numpy(w["attn_norm"]).to(DEV).to(F16), ffn_norm=torch.from_numpy(w["ffn_norm"]).to(DEV).to(F16))
+        for k in ("qkv", "o", "gate_up", "down"):
+            wd = torch.from_numpy(w[k]).to(DEV).to(F16)
+            q = torch.empty(wd.shape, dtype=torch.uint8, device=DEV)
+            s = torch.empty(wd.shape[0], dtype=torch.float32, device=DEV)
+            llmie.quantize_fp8(wd, q, s)
+            lw[k] = dict(data=q, scale=s)
+        eng8.append(lw)
+    cfg = dict(head_num=nh, kv_head_num=nh, head_size=hs, inter_size=I, num_layers=L, vocab_size=100, max_seq_len=max_seq,
+               max_batch=1, rotary_dim=hs, rotary_base=10000.0, rms_eps=1e-5, dtype=llmie.F16, wfmt=llmie.W_FP8, int4_group=128)
+    d8 = llmie.Decoder(cfg, eng8)
+    xs = torch.from_numpy(_h(rng.standard_normal((n + 1, H)).astype(np.float32))).to(DEV).to(F16)
+    z = lambda: torch.zeros((L, 1, nh, max_seq, hs), dtype=F16, device=DEV)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)
+    k1, v1, k2, v2, k3, v3 = z(), z(), z(), z(), z(), z()
+    full8 = d8.prefill(xs, torch.empty_like(xs), k1, v1, i32([n + 1]), i32([0]), n + 1).float()
+    d8.prefill(xs[:n].contiguous(), torch.empty((n, H), dtype=F16, device=DEV), k2, v2, i32([n]), i32([0]), n)
+    last = d8.forward(xs[n:n + 1].contiguous(), torch.empty((1, H), dtype=F16, device=DEV), k2, v2, n + 1).float()
+    rel = ((last - full8[n:n + 1]).norm() / full8[n:n + 1].norm()).item()
+    assert rel < 0.06, rel  # two layers = four quantisation stages of ~1.5-2% rounding chaos each
+    # rows of the first n tokens come from the same prefill arithmetic; token n's layer-1 K row carries the layer-0 noise
+    assert (k1[:, :, :, :n].float() - k2[:, :, :, :n].float()).abs().max().item() <= 2e-2
+    assert (k1.float() - k2.float()).abs().max().item() <= 0.4
+    full16 = d16.prefill(xs, torch.empty_like(xs), k3, v3, i32([n + 1]), i32([0]), n + 1).float()
+    rel16 = ((full8 - full16).norm() / full16.norm()).item()
+    assert rel16 < 0.08, rel16
+    d8.close()
+    d16.close()
