@@ -344,9 +344,9 @@ def main():
                                algorithmic_GB_per_step=round(nbytes / 1e9, 3),
                                frac_of_hbm_peak=round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
 
-        def record_prefill(name, b, s):
-            """prefill of b sequences x s tokens (packed), all 32 layers + LM head on the last token of each sequence"""
-            dec, kc, vc = make_decoder(torch, llmie, cfg, weights, weights["layers"], "f16", b, s)
+        def record_prefill(name, b, s, wfmt="f16", layers=None):
+            """prefill of b sequences x s tokens (packed), all 32 layers"""
+            dec, kc, vc = make_decoder(torch, llmie, cfg, weights, layers or weights["layers"], wfmt, b, s)
             T = b * s
             ids = torch.randint(0, V, (T,), dtype=torch.int32, device=dev)
             hid = torch.empty((T, H), dtype=torch.float16, device=dev)
@@ -368,7 +368,8 @@ def main():
             Hh, KVH, I_, L_ = H, cfg["kv_head_num"] * cfg["head_size"], cfg["inter_size"], cfg["num_layers"]
             flops = T * 2.0 * L_ * ((Hh + 2 * KVH) * Hh + Hh * Hh + 3 * Hh * I_) + b * L_ * 4.0 * Hh * s * (s + 1) / 2
             extra[name] = dict(tokens_per_s=round(T / el, 1), ms=round(el * 1e3, 3), batch=b, seq=s,
-                               TFLOP_per_s=round(flops / el / 1e12, 1), frac_of_mfma_peak=round(flops / el / 2.5e15, 4))
+                               TFLOP_per_s=round(flops / el / 1e12, 1),
+                               frac_of_mfma_peak=round(flops / el / (5.0e15 if wfmt == "fp8" else 2.5e15), 4))
             dec.close()
             del kc, vc, hid
             torch.cuda.empty_cache()
@@ -389,6 +390,8 @@ def main():
         q8f = quantize_layers(torch, llmie, weights["layers"], "fp8")   # BASELINE configs[4]: fp8 batch sweep at ctx 512
         for b in (1, 32, 128):
             record("decode_fp8_b%d_ctx512" % b, "fp8", q8f, b, 512, 1.0)
+        record_prefill("prefill_fp8_b8_s512", 8, 512, "fp8", q8f)
+        record_prefill("prefill_fp8_b1_s2048", 1, 2048, "fp8", q8f)
         del q8f
         torch.cuda.empty_cache()
         for b in (32, 128):

@@ -208,7 +208,10 @@ int llmie_linear_w4a16(const void *x, const uint8_t *wq, const void *scale, void
                        int M, int K, int N, int group, const void *bias, const void *residual,
                        llmie_stream stream);
 /* fp8 e4m3 (OCP) weights [N,K] with per-row fp32 scale; x fp16 is quantised per token to e4m3
- * on the fly (scale = amax/448); fp32 accumulate on the fp8 MFMA; y fp16 */
+ * on the fly (scale = amax/448); y[m,n] = w_scale[n] * x_scale[m] * sum_k wq[n,k] xq[m,k], fp32 accumulate; y fp16.
+ * M <= 8: K-split GEMV (same arithmetic on the VALU); 8 < M: split-K fp8 MFMA (K % 256 == 0, K >= 512);
+ * prefill-sized M x N (>= 192 tiles of 256 x 256 or 256 x 128): tiled v_mfma_scale_f32_16x16x128_f8f6f4 GEMM
+ * (K % 128 == 0).  workspace = quantised activations + per-token scales. */
 int llmie_linear_fp8(const void *x, const uint8_t *w_fp8, const float *w_scale, void *y,
                      int M, int K, int N, const void *bias, const void *residual,
                      void *workspace, size_t workspace_bytes, llmie_stream stream);
@@ -280,7 +283,8 @@ int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, void *hidde
  * context_attention.cpp:143-312) on PACKED tokens: hidden_in/out [num_tokens, H] hold the sequences back to back
  * (input_lengths[b] tokens each, device int32), history_lengths[b] tokens of each sequence are already in the caches;
  * k/v of the new tokens are appended at history+pos.  Attention is a flash kernel: causal mask from the lengths,
- * no padding buffers, no [bs,nh,q,k] score matrix.  fp16 engines with fp16 weights and head_size 128.
+ * no padding buffers, no [bs,nh,q,k] score matrix.  fp16 engines with fp16 or fp8 weights (fp8: every projection
+ * input is quantised per token, llmie_linear_fp8 semantics) and head_size 128.
  * Caches are [L, batch, kvh, max_seq, hs] with the batch of THIS call.  workspace: caller-owned scratch. */
 size_t llmie_decoder_prefill_workspace_bytes(const llmie_decoder_config *cfg, int max_tokens, int max_batch);
 int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, void *hidden_out, void *k_cache, void *v_cache,

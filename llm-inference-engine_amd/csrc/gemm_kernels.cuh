@@ -125,7 +125,7 @@ __device__ __forceinline__ half8_t permute_x_int4(const half8_t v) {
 // The first group's loads are issued before the (fused) RMSNorm prologue and the next group's loads
 // right after the dot products, before the cross-wave reduction.  The 4 waves meet once per iteration to
 // add their partial sums through a double-buffered LDS slot.
-// Measured fp16 (tools/gemv_bench.hip, MI355X, incl. ~1 us launch gap): QKV 100.7 MB 16.7 us, O 33.6 MB
+// Measured fp16 (tools/kbench.py, MI355X, incl. ~1 us launch gap): QKV 100.7 MB 16.7 us, O 33.6 MB
 // 7.6 us, down 90.2 MB 16.1 us, LM head 262 MB 42 us = 6.0 / 4.4 / 5.6 / 6.2 TB/s.
 // FP8 (WBITS == 8): e4m3 weights with fp32 per-row scales, and the activation row is quantised per token to the e4m3
 // grid in the prologue (scale amax/448, exactly quantize_rows_fp8_kernel's arithmetic) so that the result equals the
