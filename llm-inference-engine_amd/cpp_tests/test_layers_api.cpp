@@ -4,6 +4,12 @@
 #include "../src/layers/includes/context_decoder.h"
 #include "../src/layers/includes/self_decoder.h"
 #include "../src/utils/model_utils.h"
+#include <cstdlib>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <utility>
+
 #include "test_common.hpp"
 
 struct HostLayer {
@@ -260,6 +266,67 @@ template <typename T> static void run(bool fp16) {
         dec.forward(&inputs, &m.ptrs, &outputs, &dyn);
         check_close("prefill(n+1) last row == prefill(n) + decode step", to_float(dout.download()), full, rt, at);
         check_close("KV caches agree after both paths", to_float(k2.download()), to_float(k1.download()), fp16 ? rt : 1e-5f, fp16 ? at : 1e-5f);
+    }
+    {   // checkpoint loader (layer_weights.cpp:49-81, llama_weights.cpp:48-74, weight_utils.cu:189-224): per-tensor fp32 .bin
+        // files under the reference's names and HF shapes, converted to T on load
+        const int lnh = 4, lkvh = 2, lhs = 32, lI = 96, lV = 50, lL = 2, lH = lnh * lhs, lQKV = (lnh + 2 * lkvh) * lhs;
+        char tmpl[] = "/tmp/llmie_ckpt_XXXXXX";
+        const char *dir = mkdtemp(tmpl);
+        if (!dir) throw std::runtime_error("mkdtemp failed");
+        const std::string root = std::string(dir) + "/";
+        std::mt19937 wrng(77);
+        std::vector<std::pair<std::string, std::vector<float>>> files;
+        auto emit = [&](const std::string &name, size_t n) {
+            std::vector<float> v(n);
+            std::uniform_real_distribution<float> u(-1.f, 1.f);
+            for (auto &x : v) x = u(wrng);
+            FILE *f = std::fopen((root + name).c_str(), "wb");
+            if (!f || std::fwrite(v.data(), sizeof(float), n, f) != n) throw std::runtime_error("cannot write " + name);
+            std::fclose(f);
+            files.emplace_back(name, v);
+            return v;
+        };
+        const auto f_norm = emit("model.norm.weight.bin", lH);
+        const auto f_head = emit("lm_head.weight.bin", static_cast<size_t>(lV) * lH);
+        const auto f_emb = emit("model.embed_tokens.weight.bin", static_cast<size_t>(lV) * lH);
+        std::vector<std::vector<float>> f_qkv, f_o, f_gu, f_down, f_in, f_post;
+        for (int l = 0; l < lL; ++l) {
+            const std::string pre = "model.layers." + std::to_string(l);
+            f_in.push_back(emit(pre + ".input_layernorm.weight.bin", lH));
+            f_post.push_back(emit(pre + ".post_attention_layernorm.weight.bin", lH));
+            f_qkv.push_back(emit(pre + ".self_attn.qkv.weight.bin", static_cast<size_t>(lQKV) * lH));
+            f_o.push_back(emit(pre + ".self_attn.o_proj.weight.bin", static_cast<size_t>(lH) * lH));
+            f_gu.push_back(emit(pre + ".mlp.gate_up_proj.weight.bin", static_cast<size_t>(2 * lI) * lH));
+            f_down.push_back(emit(pre + ".mlp.down_proj.weight.bin", static_cast<size_t>(lH) * lI));
+        }
+        LlamaWeight<T> w(lnh, lkvh, lhs, lI, lV, lL, /*attention_bias=*/false, getWeightType<T>());
+        w.loadWeightsFromFile(root);
+        auto fetch = [&](const T *dptr, size_t n) {
+            std::vector<T> h(n);
+            CHECK(hipMemcpy(h.data(), dptr, sizeof(T) * n, hipMemcpyDeviceToHost));
+            return to_float(h);
+        };
+        auto same = [&](const char *what, const T *dptr, const std::vector<float> &file) {
+            check_close(what, fetch(dptr, file.size()), storage_round<T>(file), 0.f, 0.f);  // exact: one conversion
+        };
+        same("loader: model.norm", w.out_rmsnorm_weight.gamma, f_norm);
+        same("loader: lm_head", w.post_decoder_embedding_weight.data, f_head);
+        same("loader: embed_tokens", w.pre_decoder_embedding_weight.data, f_emb);
+        for (int l = 0; l < lL; ++l) {
+            LlamaLayerWeight<T> *lw = w.llama_layer_weight[l].get();
+            same("loader: input_layernorm", lw->attention_norm_weight.gamma, f_in[l]);
+            same("loader: post_attention_layernorm", lw->ffn_norm_weight.gamma, f_post[l]);
+            same("loader: qkv", lw->self_attention_weight.qkv.data, f_qkv[l]);
+            same("loader: o_proj", lw->self_attention_weight.output.data, f_o[l]);
+            same("loader: gate_up_proj", lw->ffn_weight.gate_and_up.data, f_gu[l]);
+            same("loader: down_proj", lw->ffn_weight.down.data, f_down[l]);
+            const bool flags = lw->self_attention_weight.qkv.is_transposed && lw->self_attention_weight.output.is_transposed &&
+                               lw->ffn_weight.gate_and_up.is_transposed && lw->ffn_weight.down.is_transposed;
+            if (!flags) { std::printf("FAIL loader: HF-layout flags\n"); ++g_failures; }
+        }
+        std::printf("checkpoint loader: %zu files round-tripped\n", files.size());
+        for (const auto &f : files) std::remove((root + f.first).c_str());
+        std::remove(dir);
     }
     {   // the user_entry.cpp flow: llm::createDummyLLMModel -> MakeInput -> Response(callback) -> MakeHistory
         llm::ModelConfig &c = llm::config();
