@@ -92,24 +92,31 @@ def quantize_layers(torch, llmie, layers, wfmt, group=128):
     return out
 
 
-def make_decoder(torch, llmie, cfg, weights, layers, wfmt, batch, max_seq):
+def make_decoder(torch, llmie, cfg, weights, layers, wfmt, batch, max_seq, kv_fp8=False):
     kv_shape = (cfg["num_layers"], batch, cfg["kv_head_num"], max_seq, cfg["head_size"])
     g = weights["gen"]
-    kc = (torch.randn(kv_shape, generator=g, device="cuda", dtype=torch.float32) * 0.5).to(torch.float16)
-    vc = (torch.randn(kv_shape, generator=g, device="cuda", dtype=torch.float32) * 0.5).to(torch.float16)
+    if kv_fp8:  # e4m3 cache bytes, stored = e4m3(x / scale): random valid codes (|x| <= 1.75 * 2^4 / 32), no NaN patterns
+        kc = torch.randint(0, 0x58, kv_shape, generator=g, device="cuda", dtype=torch.uint8)
+        vc = torch.randint(0, 0x58, kv_shape, generator=g, device="cuda", dtype=torch.uint8)
+        kc |= (torch.randint(0, 2, kv_shape, generator=g, device="cuda", dtype=torch.uint8) << 7)
+        vc |= (torch.randint(0, 2, kv_shape, generator=g, device="cuda", dtype=torch.uint8) << 7)
+    else:
+        kc = (torch.randn(kv_shape, generator=g, device="cuda", dtype=torch.float32) * 0.5).to(torch.float16)
+        vc = (torch.randn(kv_shape, generator=g, device="cuda", dtype=torch.float32) * 0.5).to(torch.float16)
     fmt = {"f16": llmie.W_F16, "int8": llmie.W_INT8, "int4": llmie.W_INT4, "fp8": llmie.W_FP8}[wfmt]
     ecfg = dict(cfg, max_seq_len=max_seq, max_batch=batch, rotary_dim=cfg["head_size"], rotary_base=10000.0,
-                rms_eps=1e-5, dtype=llmie.F16, wfmt=fmt, int4_group=128)
+                rms_eps=1e-5, dtype=llmie.F16, wfmt=fmt, int4_group=128, kv_fmt=llmie.KV_FP8 if kv_fp8 else llmie.KV_NATIVE,
+                k_scale=1.0 / 32, v_scale=1.0 / 32)
     return llmie.Decoder(ecfg, layers), kc, vc
 
 
-def decode_bytes_per_step(cfg, batch, ctx, wbytes=2.0):
-    """weights once per step (wbytes per element; LM head stays fp16) + KV read + KV append (fp16)"""
+def decode_bytes_per_step(cfg, batch, ctx, wbytes=2.0, kvbytes=2):
+    """weights once per step (wbytes per element; LM head stays fp16) + KV read + KV append (kvbytes/element)"""
     H = cfg["head_num"] * cfg["head_size"]
     KVH = cfg["kv_head_num"] * cfg["head_size"]
     I, L, V = cfg["inter_size"], cfg["num_layers"], cfg["vocab_size"]
     weights = L * ((H + 2 * KVH) * H + H * H + 3 * H * I) * wbytes + V * H * 2
-    kv = batch * L * 2 * ctx * KVH * 2 + batch * L * 2 * KVH * 2
+    kv = batch * L * 2 * ctx * KVH * kvbytes + batch * L * 2 * KVH * kvbytes
     return int(weights + kv)
 
 
@@ -212,9 +219,9 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
-    def run_decode(wfmt, layers, B, S, K, W, profile_steps, sync_ranks):
+    def run_decode(wfmt, layers, B, S, K, W, profile_steps, sync_ranks, kv_fp8=False):
         """K timed decode steps ending at context S (hipGraph replay); returns (elapsed_s, profile dict or None)"""
-        dec, kc, vc = make_decoder(torch, llmie, cfg, weights, layers, wfmt, B, S)
+        dec, kc, vc = make_decoder(torch, llmie, cfg, weights, layers, wfmt, B, S, kv_fp8)
         ids = torch.randint(0, V, (B,), dtype=torch.int32, device=dev)
         hidden = torch.empty((B, H), dtype=torch.float16, device=dev)
         logits = torch.empty((B, V), dtype=torch.float16, device=dev)
@@ -335,11 +342,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra:
         extra = {}
 
-        def record(name, wfmt, layers, b, s, wbytes):
+        def record(name, wfmt, layers, b, s, wbytes, kv_fp8=False):
             k, w_ = min(K, 32), min(W, 4)
-            el, _ = run_decode(wfmt, layers, b, s, k, w_, 0, False)
+            el, _ = run_decode(wfmt, layers, b, s, k, w_, 0, False, kv_fp8)
             ms = el / k * 1e3
-            nbytes = decode_bytes_per_step(cfg, b, s, wbytes)
+            nbytes = decode_bytes_per_step(cfg, b, s, wbytes, 1 if kv_fp8 else 2)
             extra[name] = dict(tokens_per_s=round(b * k / el, 1), ms_per_step=round(ms, 4), batch=b, ctx=s,
                                algorithmic_GB_per_step=round(nbytes / 1e9, 3),
                                frac_of_hbm_peak=round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
@@ -380,7 +387,10 @@ def main():
         q8 = quantize_layers(torch, llmie, weights["layers"], "int8")
         record("decode_int8_b1_ctx2048", "int8", q8, 1, 2048, 1.0)
         record("decode_int8_b32_ctx128", "int8", q8, 32, 128, 1.0)   # BASELINE configs[3]
+        record("decode_int8_b32_ctx2048", "int8", q8, 32, 2048, 1.0)          # KV-dominated (SURVEY 8d cfg D)
+        record("decode_int8_b32_ctx2048_kvfp8", "int8", q8, 32, 2048, 1.0, True)   # same with the e4m3 KV cache
         record("decode_f16_b1_ctx128", "f16", weights["layers"], 1, 128, 2.0)
+        record("decode_f16_b1_ctx2048_kvfp8", "f16", weights["layers"], 1, 2048, 2.0, True)
         del q8
         torch.cuda.empty_cache()
         q4 = quantize_layers(torch, llmie, weights["layers"], "int4")

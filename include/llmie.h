@@ -236,6 +236,8 @@ typedef enum {
     LLMIE_W_F32 = 4      /* fp32 weights (dtype LLMIE_F32 engines only)          */
 } llmie_weight_format;
 
+typedef enum { LLMIE_KV_NATIVE = 0, LLMIE_KV_FP8 = 1 } llmie_kv_format;
+
 typedef struct {
     const void *data;      /* [N,K] in the format's storage */
     const void *scale;     /* NULL for F16/F32 */
@@ -259,6 +261,11 @@ typedef struct {
     llmie_dtype dtype;             /* activation / KV dtype */
     llmie_weight_format wfmt;      /* storage of the 4 big matrices per layer */
     int int4_group;                /* group size for LLMIE_W_INT4 */
+    /* KV-cache storage (the reference stores T): LLMIE_KV_NATIVE = dtype, LLMIE_KV_FP8 = e4m3 bytes with one
+     * static scale per cache, stored = e4m3(x / scale), same [L, batch, kvh, max_seq, hs] indexing (fp16 engines,
+     * head_size 64/128 decode, 128 prefill, head_num/kv_head_num in {1,2,4}); a scale <= 0 means 1. */
+    llmie_kv_format kv_fmt;
+    float k_scale, v_scale;
 } llmie_decoder_config;
 
 typedef struct llmie_decoder llmie_decoder; /* opaque */

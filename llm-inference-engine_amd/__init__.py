@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libllmie.so")
 
 F32, F16 = 0, 1
 W_F16, W_INT8, W_INT4, W_FP8, W_F32 = 0, 1, 2, 3, 4
+KV_NATIVE, KV_FP8 = 0, 1
 
 _lib = None
 
@@ -296,7 +297,8 @@ class LayerWeights(C.Structure):
 class DecoderConfig(C.Structure):
     _fields_ = [("head_num", _i), ("kv_head_num", _i), ("head_size", _i), ("inter_size", _i), ("num_layers", _i),
                 ("vocab_size", _i), ("max_seq_len", _i), ("max_batch", _i), ("rotary_dim", _i),
-                ("rotary_base", _f), ("rms_eps", _f), ("dtype", _i), ("wfmt", _i), ("int4_group", _i)]
+                ("rotary_base", _f), ("rms_eps", _f), ("dtype", _i), ("wfmt", _i), ("int4_group", _i),
+                ("kv_fmt", _i), ("k_scale", _f), ("v_scale", _f)]
 
 
 def _mat(m):

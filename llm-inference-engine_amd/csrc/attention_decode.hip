@@ -16,12 +16,68 @@
 #include "llmie_internal.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace llmie {
 
+// KV cache element formats: T itself (fp32 / fp16) or e4m3 bytes (stored = e4m3(x / scale), one static scale per cache)
+struct fp8kv_t {
+    uint8_t b;
+};
+template <typename KT> struct CacheVec {
+    using type = typename Vec16<KT>::type;
+    static constexpr int n = Vec16<KT>::n;
+};
+template <> struct CacheVec<fp8kv_t> {
+    using type = uint4_t;
+    static constexpr int n = 16;
+};
+// the N elements of one 16-byte cache vector as fp32 (fp8: unscaled; the scale is folded into q / the output)
+template <typename KT, int N> __device__ __forceinline__ void kv_to_f32(const typename CacheVec<KT>::type &v, float (&o)[N]) {
+    if constexpr (std::is_same<KT, fp8kv_t>::value) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8(static_cast<int>(v[w]), false);
+            const auto hi = __builtin_amdgcn_cvt_pk_f32_fp8(static_cast<int>(v[w]), true);
+            o[4 * w] = lo[0];
+            o[4 * w + 1] = lo[1];
+            o[4 * w + 2] = hi[0];
+            o[4 * w + 3] = hi[1];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; ++e) o[e] = to_f32(v[e]);
+    }
+}
+// N values of the activation type -> one 16-byte cache vector (fp8: x * inv_scale, saturating e4m3)
+template <typename KT, typename T, int N> __device__ __forceinline__ typename CacheVec<KT>::type kv_pack(const T (&x)[N], float inv_scale) {
+    typename CacheVec<KT>::type v;
+    if constexpr (std::is_same<KT, fp8kv_t>::value) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+            v[w] = pack4_e4m3(to_f32(x[4 * w]) * inv_scale, to_f32(x[4 * w + 1]) * inv_scale, to_f32(x[4 * w + 2]) * inv_scale,
+                              to_f32(x[4 * w + 3]) * inv_scale);
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = x[e];
+    }
+    return v;
+}
+// N consecutive activation elements (N * sizeof(T) bytes = one or two 16-byte loads)
+template <typename T, int N> __device__ __forceinline__ void load_elems(const T *p, T (&dst)[N]) {
+    constexpr int PER = Vec16<T>::n;
+    static_assert(N % PER == 0, "whole 16-byte loads");
+#pragma unroll
+    for (int c = 0; c < N / PER; ++c) {
+        const typename Vec16<T>::type v = reinterpret_cast<const typename Vec16<T>::type *>(p)[c];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) dst[c * PER + e] = v[e];
+    }
+}
+
 // geometry of the split kernel: NWV waves per workgroup, GL K (and V) 16-byte loads in flight per lane
-template <typename T, int HS, int NWV = 4, int GL = 8> struct AttnGeom {
-    static constexpr int N = Vec16<T>::n;            // elements per 16-byte load
+template <typename KT, int HS, int NWV = 4, int GL = 8> struct AttnGeom {
+    static constexpr int N = CacheVec<KT>::n;        // cache elements per 16-byte load = head dims per lane
     static constexpr int LPT = HS / N;               // lanes per token row
     static constexpr int TPW = 64 / LPT;             // token rows per wave instruction
     static constexpr int CHUNK = NWV * GL * TPW;     // tokens per workgroup
@@ -70,16 +126,17 @@ __device__ __forceinline__ float merge_splits(const float *__restrict__ p, int n
     return o / (L + 1e-6f);
 }
 
-template <typename T, int HS, int REP, int kAttnWaves = 4, int kAttnG = 8>
+template <typename T, int HS, int REP, int kAttnWaves = 4, int kAttnG = 8, typename KT = T>
 __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
-    const T *__restrict__ qkv, const T *__restrict__ qkv_bias, T *k_cache, T *v_cache,
+    const T *__restrict__ qkv, const T *__restrict__ qkv_bias, KT *k_cache, KT *v_cache,
     float *__restrict__ part, T *__restrict__ out, int head_num, int kv_head_num, int max_seq_len,
     int step_arg, const int32_t *__restrict__ step_dev, int max_splits,
     const float2 *__restrict__ rope /* [max_pos][HS/2] (cos,sin) or null */, int rotary_dim,
     int32_t *tickets /* [batch, kv_head_num] zero-initialised arrival counters, or null = separate merge kernel */,
-    const QkvSlabs qs /* qs.slab != null: q/k/v come from the split-K partial slabs of the QKV projection (qkv unused) */) {
-    using G = AttnGeom<T, HS, kAttnWaves, kAttnG>;
-    using V = typename Vec16<T>::type;
+    const QkvSlabs qs /* qs.slab != null: q/k/v come from the split-K partial slabs of the QKV projection (qkv unused) */,
+    const float k_scale, const float v_scale /* fp8 cache: stored = e4m3(x / scale); 1 otherwise */) {
+    using G = AttnGeom<KT, HS, kAttnWaves, kAttnG>;
+    using V = typename CacheVec<KT>::type;  // one 16-byte vector of cache elements
     constexpr int N = G::N, LPT = G::LPT, TPW = G::TPW, CHUNK = G::CHUNK;
     constexpr int NT = kAttnWaves * 64;
     static_assert(HS % N == 0 && LPT >= 1 && LPT <= 64 && (LPT & (LPT - 1)) == 0, "head size");
@@ -100,8 +157,8 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
     const T *row = qkv + static_cast<size_t>(b) * qkv_heads * HS;
     // q for the REP heads of this kv head, pre-scaled, fp32
     const size_t head_off = (static_cast<size_t>(b) * kv_head_num + g) * max_seq_len * HS;
-    T *kc = k_cache + head_off;
-    T *vc = v_cache + head_off;
+    KT *kc = k_cache + head_off;
+    KT *vc = v_cache + head_off;
     const int t_new = step - 1;
     // small L2-resident operands first (q rows, RoPE row), then the K/V stream; q is processed after the K/V
     // loads have been issued, so its latency hides under theirs (vmcnt retires in order: q is older)
@@ -109,7 +166,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
     // the new k and v rows when its chunk holds this step's token -- are reduced ONCE per workgroup into LDS by the
     // first threads (one float4 column each, all slab loads in flight together, summed in the finalize kernel's
     // order, scaled and rounded like it) instead of by every lane (16 lanes x 4 waves hold the same q slice).
-    V qraw[REP];
+    T qraw[REP][N];
     constexpr int ITEMS_PER_HEAD = HS / 4;
     constexpr int LROUNDS = ((REP + 2) * ITEMS_PER_HEAD + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) T qkvlds[(REP + 2) * HS];
@@ -139,22 +196,22 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
         }
     } else {
 #pragma unroll
-        for (int r = 0; r < REP; ++r) qraw[r] = reinterpret_cast<const V *>(row + static_cast<size_t>(g * REP + r) * HS)[dl];
+        for (int r = 0; r < REP; ++r) load_elems<T, N>(row + static_cast<size_t>(g * REP + r) * HS + dl * N, qraw[r]);
     }
     // this step's k/v rows and the bias slices: loaded by every workgroup, unconditionally (a load under a divergent
     // or data-dependent branch makes the compiler drain vmcnt at the join -- measured: the K/V stream below used to
     // stall after its second load).  Without a bias / outside slab mode the address is a dummy valid one (the head's
     // first cache row) and the value is dropped by a select.
     const int hk = head_num + g, hv = head_num + kv_head_num + g;
-    const T *dummy = kc;
-    V knraw = reinterpret_cast<const V *>(qs.slab ? dummy : row + static_cast<size_t>(hk) * HS)[dl];
-    V vnraw = reinterpret_cast<const V *>(qs.slab ? dummy : row + static_cast<size_t>(hv) * HS)[dl];
-    V qbias[REP], kbias, vbias;
+    const T *dummy = reinterpret_cast<const T *>(kc);  // N * sizeof(T) <= 32 readable bytes at the head's first cache rows
+    T knraw[N], vnraw[N], qbias[REP][N], kbias[N], vbias[N];
+    load_elems<T, N>(qs.slab ? dummy : row + static_cast<size_t>(hk) * HS + dl * N, knraw);
+    load_elems<T, N>(qs.slab ? dummy : row + static_cast<size_t>(hv) * HS + dl * N, vnraw);
 #pragma unroll
     for (int r = 0; r < REP; ++r)
-        qbias[r] = reinterpret_cast<const V *>(qkv_bias ? qkv_bias + static_cast<size_t>(g * REP + r) * HS : dummy)[dl];
-    kbias = reinterpret_cast<const V *>(qkv_bias ? qkv_bias + static_cast<size_t>(hk) * HS : dummy)[dl];
-    vbias = reinterpret_cast<const V *>(qkv_bias ? qkv_bias + static_cast<size_t>(hv) * HS : dummy)[dl];
+        load_elems<T, N>(qkv_bias ? qkv_bias + static_cast<size_t>(g * REP + r) * HS + dl * N : dummy, qbias[r]);
+    load_elems<T, N>(qkv_bias ? qkv_bias + static_cast<size_t>(hk) * HS + dl * N : dummy, kbias);
+    load_elems<T, N>(qkv_bias ? qkv_bias + static_cast<size_t>(hv) * HS + dl * N : dummy, vbias);
     float2 csraw[N];
     if (rope) {
         const float2 *cs = rope + static_cast<size_t>(t_new) * (HS / 2) + (dl % (LPT / 2)) * N;
@@ -197,7 +254,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < REP; ++r) qraw[r] = *reinterpret_cast<const V *>(&qkvlds[r * HS + dl * N]);
+        for (int r = 0; r < REP; ++r) load_elems<T, N>(&qkvlds[r * HS + dl * N], qraw[r]);
     }
     // RoPE (fused form of launchRope, rope.cu:4-43): rotate-half pairs (d, d+HS/2) live LPT/2 lanes apart
     const bool rope_first = dl < LPT / 2;
@@ -221,10 +278,9 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
     float qf[REP][N];
 #pragma unroll
     for (int r = 0; r < REP; ++r) {
-        const V qv = qraw[r];
         float f[N];
 #pragma unroll
-        for (int e = 0; e < N; ++e) f[e] = to_f32(qv[e]);
+        for (int e = 0; e < N; ++e) f[e] = to_f32(qraw[r][e]);
         if (rope) {
             rotate(f);
 #pragma unroll
@@ -233,17 +289,22 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
 #pragma unroll
         for (int e = 0; e < N; ++e) {
             f[e] += qkv_bias ? to_f32(qbias[r][e]) : 0.f;
-            qf[r][e] = f[e] * scale;
+            qf[r][e] = f[e] * (scale * k_scale);  // the cache holds k / k_scale
         }
     }
 
     // the token of this step comes from the qkv buffer / slabs (RoPE, then +bias, as the reference's rope.cu then
     // decoder_self_attention.cu:111-118) and is appended to the cache; computed by every lane, kept by the token's lanes
     {
-        V kn = knraw, vn = vnraw;
+        T kn[N], vn[N];
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            kn[e] = knraw[e];
+            vn[e] = vnraw[e];
+        }
         if (qs.slab) {
-            kn = *reinterpret_cast<const V *>(&qkvlds[REP * HS + dl * N]);
-            vn = *reinterpret_cast<const V *>(&qkvlds[(REP + 1) * HS + dl * N]);
+            load_elems<T, N>(&qkvlds[REP * HS + dl * N], kn);
+            load_elems<T, N>(&qkvlds[(REP + 1) * HS + dl * N], vn);
         }
         if (rope) {
             float f[N];
@@ -258,20 +319,26 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
             kn[e] = qkv_bias ? from_f32<T>(to_f32(kn[e]) + to_f32(kbias[e])) : kn[e];
             vn[e] = qkv_bias ? from_f32<T>(to_f32(vn[e]) + to_f32(vbias[e])) : vn[e];
         }
+        // in the cache's element format: what is stored is what this step attends to
+        const V knv = kv_pack<KT, T, N>(kn, 1.0f / k_scale), vnv = kv_pack<KT, T, N>(vn, 1.0f / v_scale);
         bool mine = false;
 #pragma unroll
         for (int i = 0; i < kAttnG; ++i) {
             const bool is_new = tok[i] == t_new;
             mine |= is_new;
+            uint4_t kw = __builtin_bit_cast(uint4_t, kv[i]), vw = __builtin_bit_cast(uint4_t, vv[i]);
+            const uint4_t knw = __builtin_bit_cast(uint4_t, knv), vnw = __builtin_bit_cast(uint4_t, vnv);
 #pragma unroll
-            for (int e = 0; e < N; ++e) {
-                kv[i][e] = is_new ? kn[e] : kv[i][e];
-                vv[i][e] = is_new ? vn[e] : vv[i][e];
+            for (int w = 0; w < 4; ++w) {
+                kw[w] = is_new ? knw[w] : kw[w];
+                vw[w] = is_new ? vnw[w] : vw[w];
             }
+            kv[i] = __builtin_bit_cast(V, kw);
+            vv[i] = __builtin_bit_cast(V, vw);
         }
         if (mine) {
-            reinterpret_cast<V *>(kc + static_cast<size_t>(t_new) * HS)[dl] = kn;
-            reinterpret_cast<V *>(vc + static_cast<size_t>(t_new) * HS)[dl] = vn;
+            reinterpret_cast<V *>(kc + static_cast<size_t>(t_new) * HS)[dl] = knv;
+            reinterpret_cast<V *>(vc + static_cast<size_t>(t_new) * HS)[dl] = vnv;
         }
     }
 
@@ -283,12 +350,14 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
 #pragma unroll
     for (int i = 0; i < kAttnG; ++i) {
         const bool valid = tok[i] < t_end;
+        float kf[N];
+        kv_to_f32<KT, N>(kv[i], kf);
 #pragma unroll
         for (int r = 0; r < REP; ++r) {
             float d = 0.f;
             if (valid) {
 #pragma unroll
-                for (int e = 0; e < N; ++e) d = fmaf(qf[r][e], to_f32(kv[i][e]), d);
+                for (int e = 0; e < N; ++e) d = fmaf(qf[r][e], kf[e], d);
             }
             d = group_sum<LPT>(d);
             lg[r][i] = valid ? d : -INFINITY;
@@ -313,12 +382,14 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
     for (int i = 0; i < kAttnG; ++i) {
         const bool valid = tok[i] < t_end;
         if (valid) {
+            float vf[N];
+            kv_to_f32<KT, N>(vv[i], vf);
 #pragma unroll
             for (int r = 0; r < REP; ++r) {
                 const float p = __expf(lg[r][i] - mx[r]);
                 ls[r] += p;
 #pragma unroll
-                for (int e = 0; e < N; ++e) acc[r][e] = fmaf(p, to_f32(vv[i][e]), acc[r][e]);
+                for (int e = 0; e < N; ++e) acc[r][e] = fmaf(p, vf[e], acc[r][e]);
             }
         }
     }
@@ -338,7 +409,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
 #pragma unroll
         for (int r = 0; r < REP; ++r) {
 #pragma unroll
-            for (int e = 0; e < N; ++e) s_o[r][wave][dl * N + e] = acc[r][e];
+            for (int e = 0; e < N; ++e) s_o[r][wave][dl * N + e] = acc[r][e] * v_scale;  // the cache holds v / v_scale
             if (dl == 0) {
                 s_m[r][wave] = mx[r];
                 s_l[r][wave] = ls[r];
@@ -481,22 +552,26 @@ __global__ __launch_bounds__(256) void decode_attn_generic_kernel(
     }
 }
 
-template <typename T, int HS, int REP>
-static void launch_split(const T *qkv, const T *bias, T *kc, T *vc, float *part, T *out, int batch,
+struct KvScale {
+    float k, v;
+};
+
+template <typename T, int HS, int REP, typename KT = T>
+static void launch_split(const T *qkv, const T *bias, KT *kc, KT *vc, float *part, T *out, int batch,
                          int head_num, int kv_head_num, int max_seq_len, int step, const int32_t *step_dev,
                          int max_splits_ws, const float2 *rope, int rot_dim, int32_t *tickets, const QkvSlabs &qs,
-                         hipStream_t st) {
+                         KvScale ks, hipStream_t st) {
     static const int cfg = getenv("LLMIE_ATTN_CFG") ? atoi(getenv("LLMIE_ATTN_CFG")) : 0;
     const int bound = step_dev ? max_seq_len : step;
     int CHUNK, splits;
 #define LLMIE_ATTN_LAUNCH(NWV_, GL_)                                                                                   \
     do {                                                                                                                \
-        CHUNK = AttnGeom<T, HS, NWV_, GL_>::CHUNK;                                                                      \
+        CHUNK = AttnGeom<KT, HS, NWV_, GL_>::CHUNK;                                                                     \
         splits = (bound + CHUNK - 1) / CHUNK;                                                                           \
         dim3 grid(splits, kv_head_num, batch);                                                                          \
-        decode_attn_split_kernel<T, HS, REP, NWV_, GL_><<<grid, NWV_ * 64, 0, st>>>(                                    \
+        decode_attn_split_kernel<T, HS, REP, NWV_, GL_, KT><<<grid, NWV_ * 64, 0, st>>>(                                \
             qkv, bias, kc, vc, part, out, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, \
-            tickets, qs);                                                                                               \
+            tickets, qs, ks.k, ks.v);                                                                                   \
     } while (0)
     if (cfg == 1) LLMIE_ATTN_LAUNCH(8, 8);
     else if (cfg == 2) LLMIE_ATTN_LAUNCH(4, 4);
@@ -509,16 +584,18 @@ static void launch_split(const T *qkv, const T *bias, T *kc, T *vc, float *part,
     }
 }
 
-template <typename T, int HS>
-static bool dispatch_rep(int rep, const T *qkv, const T *bias, T *kc, T *vc, float *part, T *out, int batch,
+template <typename T, int HS, typename KT = T>
+static bool dispatch_rep(int rep, const T *qkv, const T *bias, KT *kc, KT *vc, float *part, T *out, int batch,
                          int head_num, int kv_head_num, int max_seq_len, int step, const int32_t *step_dev,
                          int max_splits_ws, const float2 *rope, int rot_dim, int32_t *tickets, const QkvSlabs &qs,
-                         hipStream_t st) {
+                         KvScale ks, hipStream_t st) {
     switch (rep) {
-        case 1: launch_split<T, HS, 1>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, st); return true;
-        case 2: launch_split<T, HS, 2>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, st); return true;
-        case 4: launch_split<T, HS, 4>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, st); return true;
-        case 8: launch_split<T, HS, 8>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, st); return true;
+        case 1: launch_split<T, HS, 1, KT>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, ks, st); return true;
+        case 2: launch_split<T, HS, 2, KT>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, ks, st); return true;
+        case 4: launch_split<T, HS, 4, KT>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, ks, st); return true;
+        case 8:
+            if constexpr (!std::is_same<KT, T>::value) return false;  // fp8 cache: 16 dims per lane x 8 heads does not fit registers
+            else launch_split<T, HS, 8, KT>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, ks, st); return true;
         default: return false;
     }
 }
@@ -540,13 +617,13 @@ static int decoder_mha_impl(const T *qkv, const T *bias, T *k_cache, T *v_cache,
         float *part = static_cast<float *>(workspace);
         auto ws_ok = [&]() { return workspace && workspace_bytes >= need; };
         if (head_size == 128 && ws_ok())
-            done = dispatch_rep<T, 128>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, st);
+            done = dispatch_rep<T, 128>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, KvScale{1.f, 1.f}, st);
         else if (head_size == 64 && ws_ok())
-            done = dispatch_rep<T, 64>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, st);
+            done = dispatch_rep<T, 64>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, KvScale{1.f, 1.f}, st);
         else if (head_size == 32 && ws_ok())
-            done = dispatch_rep<T, 32>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, st);
+            done = dispatch_rep<T, 32>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, KvScale{1.f, 1.f}, st);
         else if (head_size == 256 && ws_ok())
-            done = dispatch_rep<T, 256>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, st);
+            done = dispatch_rep<T, 256>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, KvScale{1.f, 1.f}, st);
         if (!done && (head_size == 128 || head_size == 64 || head_size == 32 || head_size == 256) && !ws_ok() &&
             (rep == 1 || rep == 2 || rep == 4 || rep == 8)) {
             set_error("decoder_mha: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
@@ -575,11 +652,42 @@ static int decoder_mha_impl(const T *qkv, const T *bias, T *k_cache, T *v_cache,
     return launch_status("decoder_mha");
 }
 
+// fp16 activations over an e4m3 KV cache [L, batch, kvh, max_seq, hs] bytes (stored = e4m3(x / scale)): same kernel with 16
+// cache elements per 16-byte load (8 lanes per token row, 256-token chunks); head_size 128 or 64, head ratio 1/2/4
+static int decoder_mha_fp8kv(const half_t *qkv, const half_t *bias, uint8_t *k_cache, uint8_t *v_cache, half_t *out, int layer, int batch,
+                             int head_num, int kv_head_num, int head_size, int max_seq_len, int step, const int32_t *step_dev,
+                             void *workspace, size_t workspace_bytes, const float2 *rope, int rot_dim, const QkvSlabs &qs,
+                             KvScale ks, hipStream_t st) {
+    const size_t layer_off = static_cast<size_t>(layer) * batch * kv_head_num * max_seq_len * head_size;
+    fp8kv_t *kc = reinterpret_cast<fp8kv_t *>(k_cache) + layer_off, *vc = reinterpret_cast<fp8kv_t *>(v_cache) + layer_off;
+    const int rep = head_num / kv_head_num;
+    const int max_splits_ws = (max_seq_len + attn_min_chunk() - 1) / attn_min_chunk();
+    const size_t need = llmie_decoder_mha_workspace_bytes(batch, head_num, head_size, max_seq_len);
+    if ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(kc) | reinterpret_cast<uintptr_t>(vc) |
+         reinterpret_cast<uintptr_t>(bias)) % 16 || !workspace || workspace_bytes < need || batch > 65535 || !(ks.k > 0.f) ||
+        !(ks.v > 0.f) || (rep != 1 && rep != 2 && rep != 4) || (head_size != 128 && head_size != 64)) {
+        set_error("decoder_mha(fp8 KV): needs head_size 64/128, head ratio 1/2/4, 16-byte aligned buffers, positive scales and "
+                  "the llmie_decoder_mha workspace");
+        return LLMIE_ERR_UNSUPPORTED;
+    }
+    float *part = static_cast<float *>(workspace);
+    bool done;
+    if (head_size == 128)
+        done = dispatch_rep<half_t, 128, fp8kv_t>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step,
+                                                  step_dev, max_splits_ws, rope, rot_dim, nullptr, qs, ks, st);
+    else
+        done = dispatch_rep<half_t, 64, fp8kv_t>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step,
+                                                 step_dev, max_splits_ws, rope, rot_dim, nullptr, qs, ks, st);
+    (void)done;
+    return launch_status("decoder_mha(fp8 KV)");
+}
+
 // engine entry: same as llmie_decoder_mha with RoPE (table [max_pos][hs/2] of (cos,sin)) fused in front
 int decoder_mha_rope(const void *qkv, const void *qkv_bias, void *k_cache, void *v_cache, void *out, int layer, int batch,
                      int head_num, int kv_head_num, int head_size, int max_seq_len, int step, const int32_t *step_dev,
                      void *workspace, size_t workspace_bytes, const float2 *rope, int rot_dim, int32_t *tickets,
-                     llmie_dtype dtype, hipStream_t st, const SplitKSlabs *qkv_slabs, const SlabScale *qkv_scale) {
+                     llmie_dtype dtype, hipStream_t st, const SplitKSlabs *qkv_slabs, const SlabScale *qkv_scale, int kv_fp8,
+                     float k_scale, float v_scale) {
     QkvSlabs qs{nullptr, 0, 0, SlabScale{nullptr, nullptr, nullptr}};
     const SlabScale no_scale{nullptr, nullptr, nullptr};
     const SlabScale &qsc = qkv_scale ? *qkv_scale : no_scale;
@@ -590,6 +698,15 @@ int decoder_mha_rope(const void *qkv, const void *qkv_bias, void *k_cache, void 
         return LLMIE_ERR_UNSUPPORTED;
     }
     if (qkv_slabs) qs = QkvSlabs{qkv_slabs->slab, qkv_slabs->KS, static_cast<size_t>(qkv_slabs->M) * qkv_slabs->N, qsc};
+    if (kv_fp8) {
+        if (dtype != LLMIE_F16 || tickets) {
+            set_error("decoder_mha(fp8 KV): fp16 activations, separate merge kernel only");
+            return LLMIE_ERR_UNSUPPORTED;
+        }
+        return decoder_mha_fp8kv((const half_t *)qkv, (const half_t *)qkv_bias, (uint8_t *)k_cache, (uint8_t *)v_cache, (half_t *)out,
+                                 layer, batch, head_num, kv_head_num, head_size, max_seq_len, step, step_dev, workspace,
+                                 workspace_bytes, rope, rot_dim, qs, KvScale{k_scale, v_scale}, st);
+    }
     if (dtype == LLMIE_F32)
         return decoder_mha_impl<float>((const float *)qkv, (const float *)qkv_bias, (float *)k_cache, (float *)v_cache,
                                        (float *)out, layer, batch, head_num, kv_head_num, head_size, max_seq_len, step,

@@ -75,6 +75,11 @@ static bool config_ok(const llmie_decoder_config *c) {
     if (c->dtype != LLMIE_F32 && c->dtype != LLMIE_F16) return false;
     if (c->dtype == LLMIE_F32 && c->wfmt != LLMIE_W_F32) return false;
     if (c->dtype == LLMIE_F16 && c->wfmt == LLMIE_W_F32) return false;
+    if (c->kv_fmt != LLMIE_KV_NATIVE && c->kv_fmt != LLMIE_KV_FP8) return false;
+    if (c->kv_fmt == LLMIE_KV_FP8) {  // e4m3 cache: fp16 engines on the fused attention kernels only
+        const int rep = c->head_num / c->kv_head_num;
+        if (c->dtype != LLMIE_F16 || (c->head_size != 128 && c->head_size != 64) || (rep != 1 && rep != 2 && rep != 4)) return false;
+    }
     return true;
 }
 
@@ -318,6 +323,8 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
     const bool rep_ok = rep == 1 || rep == 2 || rep == 4 || rep == 8;
     const int wbits = c.wfmt == LLMIE_W_F16 ? 16 : (c.wfmt == LLMIE_W_INT8 ? 8 : (c.wfmt == LLMIE_W_INT4 ? 4 : 0));
     const bool fp8 = c.wfmt == LLMIE_W_FP8;
+    const int kv8 = c.kv_fmt == LLMIE_KV_FP8;
+    const float k_scale = c.k_scale > 0.f ? c.k_scale : 1.f, v_scale = c.v_scale > 0.f ? c.v_scale : 1.f;
     const bool gemv_ok = wbits == 16 ? gemv_f16_eligible(batch, H, h, dec->layers[0].qkv.data)
                                      : ((wbits != 0 || fp8) && ksplit_eligible(batch, H, fp8 ? 8 : wbits));
     if (!fused_off && c.dtype == LLMIE_F16 && (wbits != 0 || fp8) && hs_ok && rep_ok && H % 8 == 0 && gemv_ok) {
@@ -361,7 +368,8 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
             TIMED(LLMIE_OP_MHA, decoder_mha_rope(dec->qkv, w.qkv.bias, k_cache, v_cache, dec->mha, l, batch, c.head_num,
                                                  c.kv_head_num, c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws,
                                                  dec->attn_ws_bytes, dec->rope_table, c.rotary_dim,
-                                                 merge_in_kernel ? dec->tickets : nullptr, dt, st));
+                                                 (merge_in_kernel && !kv8) ? dec->tickets : nullptr, dt, st, nullptr, nullptr, kv8,
+                                                 k_scale, v_scale));
             TIMED(LLMIE_OP_O_GEMM, lin(dec->mha, w.o, h, H, H, EPI_NONE_, h, nullptr, nullptr));
             TIMED(LLMIE_OP_GATE_UP_SWIGLU, lin(h, w.gate_up, dec->act, H, 2 * I, EPI_SWIGLU_, nullptr, w.ffn_norm_gamma, w.o.bias));
             TIMED(LLMIE_OP_DOWN_GEMM, lin(dec->act, w.down, h, I, H, EPI_NONE_, h, nullptr, nullptr));
@@ -408,7 +416,8 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
             const SlabScale qsc = scale_of(w.qkv, xsA);
             TIMED(LLMIE_OP_MHA, decoder_mha_rope(nullptr, w.qkv.bias, k_cache, v_cache, dec->mha, l, batch, c.head_num,
                                                  c.kv_head_num, c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws,
-                                                 dec->attn_ws_bytes, dec->rope_table, c.rotary_dim, nullptr, dt, st, &sk, &qsc));
+                                                 dec->attn_ws_bytes, dec->rope_table, c.rotary_dim, nullptr, dt, st, &sk, &qsc, kv8,
+                                                 k_scale, v_scale));
             if (fp8) TIMED(LLMIE_OP_O_GEMM, quantize_rows_fp8(mha, xqB, xsB, batch, H, st));
             TIMED(LLMIE_OP_O_GEMM, linear_splitk_partial(fmt, fp8 ? static_cast<const void *>(xqB) : mha, w.o.data, batch, H, H, st, &sk));
             // self_decoder.cpp:92  h += resid; resid = h; h += o.bias; h = rmsnorm(h, ffn_gamma)
@@ -428,6 +437,11 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
         return LLMIE_OK;
     }
 
+    if (kv8) {
+        set_error("decoder_forward: the fp8 KV cache needs the fused decode paths (batch <= 128, fp16/int8/int4/fp8 weights with "
+                  "H and I multiples of 256 at batch > 8)");
+        return LLMIE_ERR_UNSUPPORTED;
+    }
     for (int l = 0; l < c.num_layers; ++l) {
         const llmie_layer_weights &w = dec->layers[l];
         // self_decoder.cpp:77  resid = h ; h = rmsnorm(h)
@@ -533,9 +547,11 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
         const llmie_layer_weights &w = dec->layers[l];
         TIMED(LLMIE_OP_ATTN_NORM, llmie_rmsnorm(h, resid, w.attn_norm_gamma, c.rms_eps, T, H, LLMIE_F16, stream));
         TIMED(LLMIE_OP_QKV_GEMM, proj(h, w.qkv, qkv, H, QKV, nullptr));
-        TIMED(LLMIE_OP_MHA, prefill_attention_f16(qkv, (const half_t *)w.qkv.bias, (half_t *)k_cache, (half_t *)v_cache, attn, cum,
+        TIMED(LLMIE_OP_MHA, prefill_attention_f16(qkv, (const half_t *)w.qkv.bias, k_cache, v_cache, attn, cum,
                                                   history_lengths, dec->rope_table, l, batch, T, max_q_len, c.head_num,
-                                                  c.kv_head_num, c.head_size, c.max_seq_len, c.rotary_dim, st));
+                                                  c.kv_head_num, c.head_size, c.max_seq_len, c.rotary_dim, st,
+                                                  c.kv_fmt == LLMIE_KV_FP8, c.k_scale > 0.f ? c.k_scale : 1.f,
+                                                  c.v_scale > 0.f ? c.v_scale : 1.f));
         TIMED(LLMIE_OP_O_GEMM, proj(attn, w.o, h, H, H, nullptr));
         TIMED(LLMIE_OP_FFN_NORM, llmie_fused_add_bias_residual_rmsnorm(resid, h, w.o.bias, w.ffn_norm_gamma, c.rms_eps, T, H,
                                                                        LLMIE_F16, stream));

@@ -59,12 +59,14 @@ int decoder_mha_rope(const void *qkv, const void *qkv_bias, void *k_cache, void 
                      int32_t *tickets /* [batch,kvh] zeroed arrival counters: in-launch merge; null = merge kernel */,
                      llmie_dtype dtype, hipStream_t st,
                      const SplitKSlabs *qkv_slabs = nullptr /* q/k/v read from the QKV projection's split-K slabs (qkv unused) */,
-                     const SlabScale *qkv_scale = nullptr);
+                     const SlabScale *qkv_scale = nullptr,
+                     int kv_fp8 = 0 /* caches are e4m3 bytes, stored = e4m3(x / scale) */, float k_scale = 1.f, float v_scale = 1.f);
 
 // prefill attention (RoPE + KV append + flash attention) on the packed QKV buffer; prefill.hip
-int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, half_t *k_cache, half_t *v_cache, half_t *out,
+int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, void *k_cache, void *v_cache, half_t *out,
                           const int32_t *cum_seqlens, const int32_t *history_len, const float2 *rope, int layer, int batch,
                           int num_tokens, int max_q_len, int head_num, int kv_head_num, int head_size, int max_seq_len,
-                          int rotary_dim, hipStream_t st);
+                          int rotary_dim, hipStream_t st, int kv_fp8 = 0 /* caches are e4m3 bytes */, float k_scale = 1.f,
+                          float v_scale = 1.f);
 
 }  // namespace llmie

@@ -26,12 +26,19 @@ __device__ __forceinline__ void locate_token(const int32_t *__restrict__ cum, in
     pos = t - cum[lo];
 }
 
-template <int HS>
+// KV8: the caches are e4m3 bytes, stored = e4m3(x / scale) (same [L, bs, kvh, max_seq, hs] indexing in elements)
+__device__ __forceinline__ uint8_t e4m3_of(float x) {
+    x = fminf(fmaxf(x, -448.f), 448.f);
+    return static_cast<uint8_t>(__builtin_amdgcn_cvt_pk_fp8_f32(x, 0.f, 0, false) & 0xFF);
+}
+
+template <int HS, bool KV8>
 __global__ __launch_bounds__(256) void prefill_rope_append_kernel(half_t *__restrict__ qkv, const half_t *__restrict__ bias,
-                                                                  half_t *__restrict__ k_cache, half_t *__restrict__ v_cache,
+                                                                  void *__restrict__ k_cache, void *__restrict__ v_cache,
                                                                   const int32_t *__restrict__ cum, const int32_t *__restrict__ hist,
                                                                   const float2 *__restrict__ rope, int batch, int head_num,
-                                                                  int kv_head_num, int max_seq_len, int rotary_dim, size_t layer_off) {
+                                                                  int kv_head_num, int max_seq_len, int rotary_dim, size_t layer_off,
+                                                                  float k_inv_scale, float v_inv_scale) {
     const int t = blockIdx.x;
     int b, pos;
     locate_token(cum, batch, t, b, pos);
@@ -61,20 +68,29 @@ __global__ __launch_bounds__(256) void prefill_rope_append_kernel(half_t *__rest
         } else {
             const bool is_k = h < head_num + kv_head_num;
             const int g = is_k ? h - head_num : h - head_num - kv_head_num;
-            half_t *dst = (is_k ? k_cache : v_cache) + layer_off +
-                          ((static_cast<size_t>(b) * kv_head_num + g) * max_seq_len + tpos) * HS;
-            dst[d] = from_f32<half_t>(o0);
-            dst[d + HALF] = from_f32<half_t>(o1);
+            const size_t off = layer_off + ((static_cast<size_t>(b) * kv_head_num + g) * max_seq_len + tpos) * HS;
+            if constexpr (KV8) {
+                // quantise the fp16-rounded value (what the fp16 cache would hold), as the decode kernel does
+                uint8_t *dst = static_cast<uint8_t *>(is_k ? k_cache : v_cache) + off;
+                const float inv = is_k ? k_inv_scale : v_inv_scale;
+                dst[d] = e4m3_of(to_f32(from_f32<half_t>(o0)) * inv);
+                dst[d + HALF] = e4m3_of(to_f32(from_f32<half_t>(o1)) * inv);
+            } else {
+                half_t *dst = static_cast<half_t *>(is_k ? k_cache : v_cache) + off;
+                dst[d] = from_f32<half_t>(o0);
+                dst[d + HALF] = from_f32<half_t>(o1);
+            }
         }
     }
 }
 
 // grid: (q tiles of 64 rows over max_q_len, head_num, batch); block 256 = 4 waves x 16 query rows
-template <int HS>
-__global__ __launch_bounds__(256) void prefill_flash_kernel(const half_t *__restrict__ qkv, const half_t *__restrict__ k_cache,
-                                                            const half_t *__restrict__ v_cache, half_t *__restrict__ out,
+template <int HS, bool KV8>
+__global__ __launch_bounds__(256) void prefill_flash_kernel(const half_t *__restrict__ qkv, const void *__restrict__ k_cache,
+                                                            const void *__restrict__ v_cache, half_t *__restrict__ out,
                                                             const int32_t *__restrict__ cum, const int32_t *__restrict__ hist,
-                                                            int head_num, int kv_head_num, int max_seq_len, size_t layer_off) {
+                                                            int head_num, int kv_head_num, int max_seq_len, size_t layer_off,
+                                                            float k_scale, float v_scale) {
     static_assert(HS == 128, "tuned for head_size 128");
     constexpr int BQ = 64, BT = 64, VSTRIDE = HS + 4;  // V rows padded by 8 bytes (bank spread for the column gathers)
     __shared__ __attribute__((aligned(16))) half_t Ks[BT * HS];
@@ -99,8 +115,10 @@ __global__ __launch_bounds__(256) void prefill_flash_kernel(const half_t *__rest
     for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const half8_t *>(qptr + 32 * s + 8 * q);
     const int qpos = history + qrow_c;  // keys t <= qpos are visible
 
-    const half_t *kc = k_cache + layer_off + (static_cast<size_t>(b) * kv_head_num + g) * max_seq_len * HS;
-    const half_t *vc = v_cache + layer_off + (static_cast<size_t>(b) * kv_head_num + g) * max_seq_len * HS;
+    const size_t head_off = layer_off + (static_cast<size_t>(b) * kv_head_num + g) * max_seq_len * HS;
+    const half_t *kc = static_cast<const half_t *>(k_cache) + head_off, *vc = static_cast<const half_t *>(v_cache) + head_off;
+    const uint8_t *kc8 = static_cast<const uint8_t *>(k_cache) + head_off, *vc8 = static_cast<const uint8_t *>(v_cache) + head_off;
+    (void)kc; (void)vc; (void)kc8; (void)vc8;
 
     floatx4 o[8];  // O^T tiles: rows d = 16*dt + 4q + e, col = this lane's query row
 #pragma unroll
@@ -115,8 +133,25 @@ __global__ __launch_bounds__(256) void prefill_flash_kernel(const half_t *__rest
         for (int i = 0; i < 4; ++i) {
             const int id = tid + 256 * i, row = id >> 4, ch = id & 15;
             const int t = min(t0 + row, ctx - 1);
-            const half8_t kvv = *reinterpret_cast<const half8_t *>(kc + static_cast<size_t>(t) * HS + ch * 8);
-            const half8_t vvv = *reinterpret_cast<const half8_t *>(vc + static_cast<size_t>(t) * HS + ch * 8);
+            half8_t kvv, vvv;
+            if constexpr (KV8) {
+                // 8 e4m3 bytes -> 8 halves (x scale): the tiles in LDS are fp16 either way
+                const uint2 kb = *reinterpret_cast<const uint2 *>(kc8 + static_cast<size_t>(t) * HS + ch * 8);
+                const uint2 vb = *reinterpret_cast<const uint2 *>(vc8 + static_cast<size_t>(t) * HS + ch * 8);
+                const half2_t k0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(kb.x), k_scale, false);
+                const half2_t k1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(kb.x), k_scale, true);
+                const half2_t k2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(kb.y), k_scale, false);
+                const half2_t k3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(kb.y), k_scale, true);
+                const half2_t v0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(vb.x), v_scale, false);
+                const half2_t v1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(vb.x), v_scale, true);
+                const half2_t v2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(vb.y), v_scale, false);
+                const half2_t v3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(vb.y), v_scale, true);
+                kvv = half8_t{k0[0], k0[1], k1[0], k1[1], k2[0], k2[1], k3[0], k3[1]};
+                vvv = half8_t{v0[0], v0[1], v1[0], v1[1], v2[0], v2[1], v3[0], v3[1]};
+            } else {
+                kvv = *reinterpret_cast<const half8_t *>(kc + static_cast<size_t>(t) * HS + ch * 8);
+                vvv = *reinterpret_cast<const half8_t *>(vc + static_cast<size_t>(t) * HS + ch * 8);
+            }
             *reinterpret_cast<half8_t *>(Ks + row * HS + ((ch ^ (row & 15)) << 3)) = kvv;
             *reinterpret_cast<half4_t *>(Vs + row * VSTRIDE + ch * 8) = half4_t{vvv[0], vvv[1], vvv[2], vvv[3]};
             *reinterpret_cast<half4_t *>(Vs + row * VSTRIDE + ch * 8 + 4) = half4_t{vvv[4], vvv[5], vvv[6], vvv[7]};
@@ -193,20 +228,29 @@ __global__ __launch_bounds__(256) void prefill_flash_kernel(const half_t *__rest
     }
 }
 
-int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, half_t *k_cache, half_t *v_cache, half_t *out,
+int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, void *k_cache, void *v_cache, half_t *out,
                           const int32_t *cum_seqlens, const int32_t *history_len, const float2 *rope, int layer, int batch,
                           int num_tokens, int max_q_len, int head_num, int kv_head_num, int head_size, int max_seq_len,
-                          int rotary_dim, hipStream_t st) {
+                          int rotary_dim, hipStream_t st, int kv_fp8, float k_scale, float v_scale) {
     if (head_size != 128) {
         set_error("prefill attention: head_size %d not supported by the flash kernel (128 only)", head_size);
         return LLMIE_ERR_UNSUPPORTED;
     }
     const size_t layer_off = static_cast<size_t>(layer) * batch * kv_head_num * max_seq_len * head_size;
-    prefill_rope_append_kernel<128><<<num_tokens, 256, 0, st>>>(qkv, qkv_bias, k_cache, v_cache, cum_seqlens, history_len, rope,
-                                                                batch, head_num, kv_head_num, max_seq_len, rotary_dim, layer_off);
     dim3 grid((max_q_len + 63) / 64, head_num, batch);
-    prefill_flash_kernel<128><<<grid, 256, 0, st>>>(qkv, k_cache, v_cache, out, cum_seqlens, history_len, head_num, kv_head_num,
-                                                    max_seq_len, layer_off);
+    if (kv_fp8) {
+        prefill_rope_append_kernel<128, true><<<num_tokens, 256, 0, st>>>(qkv, qkv_bias, k_cache, v_cache, cum_seqlens, history_len,
+                                                                          rope, batch, head_num, kv_head_num, max_seq_len,
+                                                                          rotary_dim, layer_off, 1.0f / k_scale, 1.0f / v_scale);
+        prefill_flash_kernel<128, true><<<grid, 256, 0, st>>>(qkv, k_cache, v_cache, out, cum_seqlens, history_len, head_num,
+                                                              kv_head_num, max_seq_len, layer_off, k_scale, v_scale);
+    } else {
+        prefill_rope_append_kernel<128, false><<<num_tokens, 256, 0, st>>>(qkv, qkv_bias, k_cache, v_cache, cum_seqlens, history_len,
+                                                                           rope, batch, head_num, kv_head_num, max_seq_len,
+                                                                           rotary_dim, layer_off, 1.f, 1.f);
+        prefill_flash_kernel<128, false><<<grid, 256, 0, st>>>(qkv, k_cache, v_cache, out, cum_seqlens, history_len, head_num,
+                                                               kv_head_num, max_seq_len, layer_off, 1.f, 1.f);
+    }
     return launch_status("prefill_attention");
 }
 
