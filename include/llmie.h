@@ -216,6 +216,11 @@ int llmie_linear_fp8(const void *x, const uint8_t *w_fp8, const float *w_scale, 
                      int M, int K, int N, const void *bias, const void *residual,
                      void *workspace, size_t workspace_bytes, llmie_stream stream);
 size_t llmie_linear_fp8_workspace_bytes(int M, int K);
+/* y[M, two_inter/2] = silu(gate) * up of the fused gate_up projection in fp8 (ffn.cpp:105-122 in one launch after the
+ * activation quantisation); prefill-sized shapes only (LLMIE_ERR_UNSUPPORTED otherwise: use llmie_linear_fp8 +
+ * llmie_silu_and_mul) */
+int llmie_linear_fp8_swiglu(const void *x, const uint8_t *w_fp8, const float *w_scale, void *y, int M, int K,
+                            int two_inter, void *workspace, size_t workspace_bytes, llmie_stream stream);
 /* offline quantisers (device side): w fp16 [N,K] -> int8/int4/fp8 + scales */
 int llmie_quantize_w8(const void *w, int8_t *wq, void *scale, int N, int K, llmie_stream stream);
 int llmie_quantize_w4(const void *w, uint8_t *wq, void *scale, int N, int K, int group,

@@ -65,6 +65,7 @@ _SIGS = {
     "llmie_linear_w4a16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "llmie_linear_fp8": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp],
     "llmie_linear_fp8_workspace_bytes": [_i, _i],
+    "llmie_linear_fp8_swiglu": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp],
     "llmie_quantize_w8": [_vp, _vp, _vp, _i, _i, _vp],
     "llmie_quantize_w4": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "llmie_quantize_fp8": [_vp, _vp, _vp, _i, _i, _vp],
@@ -410,6 +411,12 @@ def quantize_fp8(w, wq, scale):
 
 def linear_fp8_workspace_bytes(M, K):
     return lib().llmie_linear_fp8_workspace_bytes(M, K)
+
+
+def linear_fp8_swiglu(x, wq, wscale, y, workspace):
+    _check(lib().llmie_linear_fp8_swiglu(_p(x), _p(wq), _p(wscale), _p(y), x.shape[0], x.shape[1], wq.shape[0], _p(workspace),
+                                         workspace.numel() * workspace.element_size(), _st()), "linear_fp8_swiglu")
+    return y
 
 
 def linear_fp8(x, wq, wscale, y, workspace, bias=None, residual=None):

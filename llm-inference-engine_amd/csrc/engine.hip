@@ -555,8 +555,16 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
         TIMED(LLMIE_OP_O_GEMM, proj(attn, w.o, h, H, H, nullptr));
         TIMED(LLMIE_OP_FFN_NORM, llmie_fused_add_bias_residual_rmsnorm(resid, h, w.o.bias, w.ffn_norm_gamma, c.rms_eps, T, H,
                                                                        LLMIE_F16, stream));
-        TIMED(LLMIE_OP_GATE_UP_SWIGLU, proj(h, w.gate_up, gu, H, 2 * I, nullptr));
-        TIMED(LLMIE_OP_GATE_UP_SWIGLU, llmie_silu_and_mul(gu, act, T, I, LLMIE_F16, stream));
+        // ffn.cpp:105-122: act = silu(h.Wg^T) * (h.Wu^T); SwiGLU fused into the projection's epilogue where a fused form exists
+        if (!fp8 && (T <= 192 || gemm256_swiglu_fills(T, 2 * I))) {
+            TIMED(LLMIE_OP_GATE_UP_SWIGLU, linear_f16_nk(h, (const half_t *)w.gate_up.data, act, T, H, 2 * I, EPI_SWIGLU_, nullptr, nullptr, st));
+        } else if (fp8 && gemm256_swiglu_fills(T, 2 * I) && H % 128 == 0 && reinterpret_cast<uintptr_t>(w.gate_up.data) % 16 == 0) {
+            TIMED(LLMIE_OP_GATE_UP_SWIGLU, llmie_linear_fp8_swiglu(h, (const uint8_t *)w.gate_up.data, (const float *)w.gate_up.scale,
+                                                                   act, T, H, 2 * I, f8ws, f8ws_bytes, stream));
+        } else {
+            TIMED(LLMIE_OP_GATE_UP_SWIGLU, proj(h, w.gate_up, gu, H, 2 * I, nullptr));
+            TIMED(LLMIE_OP_GATE_UP_SWIGLU, llmie_silu_and_mul(gu, act, T, I, LLMIE_F16, stream));
+        }
         TIMED(LLMIE_OP_DOWN_GEMM, proj(act, w.down, h, I, H, resid));
     }
     return LLMIE_OK;

@@ -113,3 +113,25 @@ extern "C" int llmie_linear_fp8(const void *x, const uint8_t *w_fp8, const float
     }
     return launch_status("linear_fp8");
 }
+
+extern "C" int llmie_linear_fp8_swiglu(const void *x, const uint8_t *w_fp8, const float *w_scale, void *y, int M, int K,
+                                       int two_inter, void *workspace, size_t workspace_bytes, llmie_stream stream) {
+    LLMIE_REQUIRE(x && w_fp8 && w_scale && y && workspace, "linear_fp8_swiglu: NULL pointer");
+    LLMIE_REQUIRE(M > 0 && K > 0 && two_inter > 0 && two_inter % 2 == 0, "linear_fp8_swiglu: bad shape");
+    if (!gemm256_swiglu_fills(M, two_inter) || K % 128 != 0 || reinterpret_cast<uintptr_t>(w_fp8) % 16 ||
+        reinterpret_cast<uintptr_t>(workspace) % 256 || reinterpret_cast<uintptr_t>(y) % 8)
+        LLMIE_UNSUPPORTED("linear_fp8_swiglu: prefill-sized shapes only (>= 192 tiles of 256 tokens x 128 columns, K %% 128 == 0, "
+                          "two_inter %% 8 == 0); use llmie_linear_fp8 + llmie_silu_and_mul otherwise");
+    if (workspace_bytes < llmie_linear_fp8_workspace_bytes(M, K)) {
+        set_error("linear_fp8_swiglu: workspace too small");
+        return LLMIE_ERR_WORKSPACE;
+    }
+    hipStream_t st = as_stream(stream);
+    uint8_t *xq = static_cast<uint8_t *>(workspace);
+    float *xscale = reinterpret_cast<float *>(xq + fp8_align(static_cast<size_t>(M) * K));
+    const int rc = quantize_rows_fp8((const half_t *)x, xq, xscale, M, K, st);
+    if (rc) return rc;
+    gemm256_swiglu_launch(true, xq, w_fp8, (half_t *)y, M, two_inter, K, xscale, w_scale, st);
+    return launch_status("linear_fp8_swiglu");
+}
+

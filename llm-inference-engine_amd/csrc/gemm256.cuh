@@ -24,15 +24,21 @@ typedef int intx8 __attribute__((ext_vector_type(8)));
 
 // WN = MFMA column tiles per wave: 4 -> 256 x 256 workgroup tile, 2 -> 256 x 128 (one W half per stage, 96 KiB of LDS) for
 // projections whose 256-wide grid would leave CUs idle (N = 4096 at 2048 tokens: 128 vs 256 workgroups).
-template <bool FP8, bool HAS_EPI, int WN = 4>
+// SWIGLU (WN = 4, W = fused gate_up [2I, K]): the workgroup's 256 weight rows are 128 gate rows n0 .. and the 128 up rows
+// I + n0 .. of the same columns; every wave multiplies 32 gate and the matching 32 up columns of its 128 tokens, so
+// act = silu(gate) * up is formed in registers and C is [M, I] -- the [M, 2I] intermediate and the SiluAndMul pass
+// (silu_and_mul.cu:61-82) never touch memory.
+template <bool FP8, bool HAS_EPI, int WN = 4, bool SWIGLU = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(const void *__restrict__ Xv, const void *__restrict__ Wv, half_t *C,
                                                       int M, int N, int K, const half_t *__restrict__ bias,
                                                       const half_t *residual, int tiles_n, const float *__restrict__ xscale,
                                                       const float *__restrict__ wscale) {
     constexpr int ES = FP8 ? 1 : 2;            // bytes per element
     constexpr int BK = 128 / ES;               // k per tile: rows of 128 bytes either way
-    constexpr int BN = 64 * WN;                // workgroup tile columns
-    constexpr int NHALF = 2 + BN / 128;        // 128-row half tiles per stage: X0 X1 W0 [W1]
+    static_assert(!SWIGLU || (WN == 4 && !HAS_EPI), "SwiGLU form: 256 weight rows = 128 gate + 128 up, no bias/residual");
+    constexpr int BN = SWIGLU ? 128 : 64 * WN;  // workgroup tile columns of C
+    const int half_n = N >> 1;                 // SWIGLU: I (N = 2I weight rows)
+    constexpr int NHALF = SWIGLU ? 4 : 2 + BN / 128;  // 128-row half tiles per stage: X0 X1 W0 [W1]  (SWIGLU: X0 X1 gate up)
     constexpr int HALF_BYTES = 128 * 128, STAGE_BYTES = NHALF * HALF_BYTES;
     const unsigned char *X = static_cast<const unsigned char *>(Xv), *W = static_cast<const unsigned char *>(Wv);
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];  // [2][4][128 * 128]
@@ -52,7 +58,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const void *__restrict__ X
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = (i * 8 + wave) * 8 + (lane >> 3), slot = lane & 7, chunk = slot ^ (row & 7);
-            const int grow = h < 2 ? min(m0 + h * 128 + row, M - 1) : min(n0 + (h - 2) * 128 + row, N - 1);  // clamped: never stored
+            int grow;  // clamped: edge rows are never stored
+            if (h < 2) grow = min(m0 + h * 128 + row, M - 1);
+            else if (SWIGLU) grow = (h - 2) * half_n + min(n0 + row, half_n - 1);  // half 2: gate rows, half 3: up rows
+            else grow = min(n0 + (h - 2) * 128 + row, N - 1);
             src[h][i] = (h < 2 ? X : W) + static_cast<size_t>(grow) * K * ES + chunk * 16;
         }
     auto dma_tile = [&](int kt, int stage) {
@@ -75,9 +84,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const void *__restrict__ X
 
     // fragment addresses inside a stage: X row-tile i of this wave -> half wr, row i*16 + r; W col-tile j -> half 2 + (wc >> 1),
     // row (wc & 1) * 64 + j*16 + r; chunk c = ks*4 + q sits in slot c ^ (row & 7)
-    const int wcol = wc * 16 * WN;  // first column of this wave inside the workgroup tile
+    const int wcol = SWIGLU ? wc * 32 : wc * 16 * WN;  // first column of this wave inside the workgroup tile
     const int a_row0 = r, b_row0 = (wcol & 127) + r;
-    const unsigned char *a_base = lds + wr * HALF_BYTES, *b_base = lds + (2 + (wcol >> 7)) * HALF_BYTES;
+    const unsigned char *a_base = lds + wr * HALF_BYTES, *b_base = lds + (2 + (SWIGLU ? 0 : (wcol >> 7))) * HALF_BYTES;
+    // B fragment j of this wave: plain -> row b_row0 + 16 j of its half; SWIGLU -> j = 0,1 gate rows (half 2), j = 2,3 the same
+    // rows of the up half (half 3)
+    auto b_off = [&](int j) { return SWIGLU ? (j >> 1) * HALF_BYTES : 0; };
+    auto b_row = [&](int j) { return SWIGLU ? b_row0 + (j & 1) * 16 : b_row0 + j * 16; };
     auto frag = [&](const unsigned char *base, int row, int c) {
         return *reinterpret_cast<const half8_t *>(base + row * 128 + ((c ^ (row & 7)) << 4));
     };
@@ -99,7 +112,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const void *__restrict__ X
             };
             intx8 bf[WN];
 #pragma unroll
-            for (int j = 0; j < WN; ++j) bf[j] = frag8(bb, b_row0 + j * 16);
+            for (int j = 0; j < WN; ++j) bf[j] = frag8(bb + b_off(j), b_row(j));
 #pragma unroll
             for (int ih = 0; ih < 2; ++ih) {
                 intx8 af[4];
@@ -117,7 +130,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const void *__restrict__ X
         for (int ks = 0; ks < 2; ++ks) {
             half8_t bf[WN];
 #pragma unroll
-            for (int j = 0; j < WN; ++j) bf[j] = frag(bb, b_row0 + j * 16, ks * 4 + q);
+            for (int j = 0; j < WN; ++j) bf[j] = frag(bb + b_off(j), b_row(j), ks * 4 + q);
 #pragma unroll
             for (int ih = 0; ih < 2; ++ih) {
                 half8_t af[4];
@@ -135,6 +148,41 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const void *__restrict__ X
         __syncthreads();  // every wave done with this stage; the next stage's DMA has landed (the barrier drains vmcnt)
     }
 
+    if constexpr (SWIGLU) {
+        // acc[i][jj] = gate, acc[i][2 + jj] = up of C columns n0 + wcol + 16 jj + 4q + e
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + wr * 128 + i * 16 + r;
+            if (m >= M) continue;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int n = n0 + wcol + jj * 16 + 4 * q;
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float gt = acc[i][jj][e], up = acc[i][2 + jj][e];
+                    if constexpr (FP8) {
+                        const float xsm = xscale[m];
+                        gt *= wscale[min(n + e, half_n - 1)] * xsm;
+                        up *= wscale[half_n + min(n + e, half_n - 1)] * xsm;
+                    }
+                    // the unfused sequence rounds gate and up to fp16 before SiluAndMul: keep the same roundings
+                    gt = to_f32(from_f32<half_t>(gt));
+                    up = to_f32(from_f32<half_t>(up));
+                    o[e] = (gt / (1.0f + expf(-gt))) * up;
+                }
+                if (n + 3 < half_n && (half_n & 3) == 0) {
+                    const half4_t o4 = {from_f32<half_t>(o[0]), from_f32<half_t>(o[1]), from_f32<half_t>(o[2]), from_f32<half_t>(o[3])};
+                    *reinterpret_cast<half4_t *>(C + static_cast<size_t>(m) * half_n + n) = o4;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < half_n) C[static_cast<size_t>(m) * half_n + n + e] = from_f32<half_t>(o[e]);
+                }
+            }
+        }
+        return;
+    }
     // acc[i][j]: lane holds C[m0 + wr*128 + i*16 + r][n0 + wcol + j*16 + 4q + e]
 #pragma unroll
     for (int i = 0; i < 8; ++i) {

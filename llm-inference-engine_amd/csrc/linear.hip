@@ -413,6 +413,30 @@ static void gemm256_launch_t(const void *x, const void *W, half_t *y, int M, int
     gemm256_kernel<FP8, EPI, WN><<<tm * tn, 512, lds_bytes, st>>>(x, W, y, M, N, K, bias, residual, tn, xscale, wscale);
 }
 
+// SwiGLU form: W = fused gate_up [2I, K], y = silu(x.Wg^T) * (x.Wu^T) [M, I]
+bool gemm256_swiglu_fills(int M, int two_inter) {
+    static const int min_tiles = env_int("LLMIE_GEMM256_MIN_TILES", 192);
+    static const bool off = getenv("LLMIE_GEMM256_NO_SWIGLU") != nullptr;
+    return !off && two_inter % 8 == 0 && ((M + 255) / 256) * ((two_inter / 2 + 127) / 128) >= min_tiles;
+}
+void gemm256_swiglu_launch(bool fp8, const void *x, const void *W, half_t *y, int M, int two_inter, int K, const float *xscale,
+                           const float *wscale, hipStream_t st) {
+    constexpr int lds_bytes = 2 * 4 * 128 * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm256_kernel<false, false, 4, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm256_kernel<true, false, 4, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        attr_set = true;
+    }
+    const int tm = (M + 255) / 256, tn = (two_inter / 2 + 127) / 128;
+    if (fp8)
+        gemm256_kernel<true, false, 4, true><<<tm * tn, 512, lds_bytes, st>>>(x, W, y, M, two_inter, K, nullptr, nullptr, tn, xscale, wscale);
+    else
+        gemm256_kernel<false, false, 4, true><<<tm * tn, 512, lds_bytes, st>>>(x, W, y, M, two_inter, K, nullptr, nullptr, tn, nullptr, nullptr);
+}
+
 void gemm256_launch(bool fp8, const void *x, const void *W, half_t *y, int M, int N, int K, const half_t *bias,
                     const half_t *residual, const float *xscale, const float *wscale, hipStream_t st) {
     const int wn = gemm256_wn(M, N) == 2 ? 2 : 4;
@@ -444,6 +468,10 @@ int linear_f16_nk(const half_t *x, const half_t *W, half_t *y, int M, int K, int
     if (!done && aligned && M <= 64 && K % 32 == 0 && (epi != EPI_SWIGLU || (N / 2) % 16 == 0)) {
         done = (epi == EPI_SWIGLU) ? dispatch_skinny<EPI_SWIGLU>(M, x, W, y, K, N, bias, residual, st)
                                    : dispatch_skinny<EPI_NONE>(M, x, W, y, K, N, bias, residual, st);
+    }
+    if (!done && epi == EPI_SWIGLU && aligned && K % 64 == 0 && gemm256_swiglu_fills(M, N) && reinterpret_cast<uintptr_t>(y) % 8 == 0) {
+        gemm256_swiglu_launch(false, x, W, y, M, N, K, nullptr, nullptr, st);
+        return launch_status("linear(gemm256 SwiGLU)");
     }
     if (!done && epi == EPI_SWIGLU) {
         set_error("linear: fused SwiGLU epilogue needs M<=64, K%%32==0, (N/2)%%16==0 (M=%d K=%d N=%d)", M, K, N);

@@ -38,6 +38,9 @@ int linear_splitk(int wbits, const half_t *x, const void *W, const half_t *scale
 bool gemm256_fills(int M, int N);
 void gemm256_launch(bool fp8, const void *x, const void *W, half_t *y, int M, int N, int K, const half_t *bias,
                     const half_t *residual, const float *xscale, const float *wscale, hipStream_t st);
+bool gemm256_swiglu_fills(int M, int two_inter);
+void gemm256_swiglu_launch(bool fp8, const void *x, const void *W, half_t *y, int M, int two_inter, int K, const float *xscale,
+                           const float *wscale, hipStream_t st);
 // quantised-weight (int8 / int4) decode GEMV on the K-split kernel; defined in linear.hip
 struct GemvArgs;
 bool ksplit_eligible(int M, int K, int wbits);

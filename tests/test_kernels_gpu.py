@@ -236,6 +236,23 @@ def test_linear_gemm256(llmie, M, K, N, epi):
         close(host(y), orc.linear(x, w), 2e-3, 2e-3)
 
 
+@pytest.mark.parametrize("M,K,I", [(4096, 128, 3072), (4000, 192, 3100), (300, 256, 344)])
+def test_linear_swiglu_large_m(llmie, M, K, I):
+    """ffn.cpp:105-122 in one launch at prefill sizes: the 256-token tile multiplies 128 gate and the matching 128 up rows
+    and forms silu(gate) * up in registers (gemm256.cuh SWIGLU form); the small case falls back to ... an error unless a
+    fused form exists, so it is skipped when unsupported"""
+    rng = np.random.default_rng(M + I)
+    x, w = rnd(rng, (M, K), 1.0, torch.float16), rnd(rng, (2 * I, K), 1.0 / np.sqrt(K), torch.float16)
+    y = torch.full((M, I), 99.0, dtype=torch.float16, device=DEV)
+    try:
+        llmie.linear_swiglu(dev(x, torch.float16), dev(w, torch.float16), y)
+    except llmie.LlmieError:
+        assert M < 1000  # only the shapes without a fused form may refuse
+        return
+    gu = np.float16(orc.linear(x, w)).astype(np.float32)  # the projection output is rounded to fp16 before SiluAndMul
+    close(host(y), orc.silu_and_mul(gu.reshape(M, 2, I)), 3e-3, 3e-3)
+
+
 @pytest.mark.parametrize("M", [1, 4, 20, 150])
 def test_linear_fused_bias_residual(llmie, M):
     rng = np.random.default_rng(9)

@@ -211,6 +211,26 @@ def test_linear_fp8(llmie, M, K, N):
     assert np.abs(y.float().cpu().numpy() - ref).max() <= 0.12 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("M,K,I", [(4096, 256, 3072), (3990, 384, 3100)])
+def test_linear_fp8_swiglu(llmie, M, K, I):
+    rng = np.random.default_rng(55)
+    w = _h(rng.standard_normal((2 * I, K)).astype(np.float32) / np.sqrt(K))
+    x = _h(rng.standard_normal((M, K)).astype(np.float32))
+    wd = torch.from_numpy(w).to(DEV).to(F16)
+    wq = torch.empty((2 * I, K), dtype=torch.uint8, device=DEV)
+    ws = torch.empty(2 * I, dtype=torch.float32, device=DEV)
+    llmie.quantize_fp8(wd, wq, ws)
+    work = torch.empty(llmie.linear_fp8_workspace_bytes(M, K), dtype=torch.uint8, device=DEV)
+    y = torch.empty((M, I), dtype=F16, device=DEV)
+    llmie.linear_fp8_swiglu(torch.from_numpy(x).to(DEV).to(F16), wq, ws, y, work)
+    tab = _e4m3_table()
+    wdeq = tab[wq.cpu().numpy()] * ws.cpu().numpy()[:, None]
+    gu = _h(_fp8_lin(x, wdeq))
+    exp = orc.silu_and_mul(gu.reshape(M, 2, I))
+    err = np.abs(y.float().cpu().numpy() - exp)
+    assert (err <= 4e-3 + 4e-3 * np.abs(exp)).all(), err.max()
+
+
 def _fp8_lin(x, wdeq):
     """fp8 projection as the engine defines it: per-token e4m3 activations (scale amax/448) x de-quantised e4m3 weights"""
     xs = (np.abs(x).max(axis=1) / np.float32(448.0)).astype(np.float32)

@@ -29,6 +29,14 @@ if "prefill" in sys.argv:
             W = [(torch.randn((N, K), device=dev) / K ** 0.5).half() for _ in range(4)]
             t = timeit(lambda i: llmie.linear(x, W[i % 4], y), n=8)
             print("M=%d %-8s f16 %8.1f us  %6.1f TFLOP/s" % (M, name, t, 2.0 * M * N * K / t / 1e6))
+            if name == "gate_up":
+                y2 = torch.empty((M, N // 2), device=dev, dtype=torch.float16)
+                t2 = timeit(lambda i: llmie.silu_and_mul(y.view(M, 2, N // 2), y2), n=8)
+                try:
+                    t3 = timeit(lambda i: llmie.linear_swiglu(x, W[i % 4], y2), n=8)
+                    print("M=%d %-8s f16 SiluAndMul alone %6.1f us; fused projection+SwiGLU %8.1f us  %6.1f TFLOP/s" % (M, name, t2, t3, 2.0 * M * N * K / t3 / 1e6))
+                except llmie.LlmieError:
+                    print("M=%d %-8s f16 SiluAndMul alone %6.1f us; no fused form at this size" % (M, name, t2))
             Q = []
             for w in W:
                 q = torch.empty((N, K), dtype=torch.uint8, device=dev); sc = torch.empty(N, dtype=torch.float32, device=dev)
