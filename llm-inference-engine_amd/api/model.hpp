@@ -7,31 +7,9 @@
 #include <functional>
 
 #include "layers.hpp"
+#include "tokenizer.hpp"
 
 using CallBack = std::function<void(int, const char *)>;
-
-// Minimal stand-in for src/models/tokenizer.h (out of scope: CPU string code, no vocabulary file is
-// available offline).  Encode() returns the prompt ids the reference hard-codes
-// (llama.cpp:328,340); Decode() prints ids as text.
-class Tokenizer {
-public:
-    bool loaded = false;
-    std::string path;
-    void Initialize(const std::string &file) {
-        path = file;
-        std::ifstream in(file, std::ios::binary);
-        loaded = in.is_open();
-        if (!loaded) std::cerr << "[llmie] tokenizer file " << file << " not found: token ids are printed as <id>\n";
-    }
-    std::vector<int> Encode(const std::string &) const {
-        return {1, 18637, 29892, 526, 366, 19861, 29973, 1815, 366, 5193, 304, 592, 29973};
-    }
-    std::string Decode(const std::vector<int> &ids) const {
-        std::string s;
-        for (int id : ids) s += "<" + std::to_string(id) + ">";
-        return s;
-    }
-};
 
 class BaseModel {
 public:

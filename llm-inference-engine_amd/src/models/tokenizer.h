@@ -1,3 +1,3 @@
-// Same relative path as the reference header; the implementation lives in api/model.hpp
+// Same relative path as the reference header (src/models/tokenizer.h); the implementation lives in api/tokenizer.hpp
 #pragma once
-#include "../../api/model.hpp"
+#include "../../api/tokenizer.hpp"
