@@ -124,3 +124,39 @@ def test_int8_engine_tracks_fp16_engine(llmie, full):
     assert rel.item() < 0.10, rel.item()  # per-row int8 weight noise (~0.4 % per GEMM) through 32 layers
     d16.close()
     d8.close()
+
+
+@pytest.mark.parametrize("wfmt,batch,kv8", [("int8", 32, False), ("f16", 16, True), ("fp8", 24, False)])
+def test_batch_path_graph_replay_equals_eager_and_rows_are_symmetric(llmie, full, wfmt, batch, kv8):
+    """fused batch decode path (split-K slabs in the library's scratch, consumed by the attention / row kernels): a captured
+    graph replays bit-identically to the eager launches, identical sequences in a batch give identical rows, all 32 layers"""
+    bench, cfg, weights = full
+    layers = weights["layers"] if wfmt == "f16" else bench.quantize_layers(torch, llmie, weights["layers"], wfmt)
+    dec, kc, vc = bench.make_decoder(torch, llmie, cfg, weights, layers, wfmt, batch, 384, kv8)
+    kc[:, 1:] = kc[:, :1]
+    vc[:, 1:] = vc[:, :1]
+    x = torch.randn((1, 4096), device=DEV).to(F16).repeat(batch, 1).contiguous()
+    step_dev = torch.tensor([260], dtype=torch.int32, device=DEV)
+    k0, v0 = kc.clone(), vc.clone()
+    eager = dec.forward(x, torch.empty_like(x), kc, vc, -1, step_dev=step_dev).clone()
+    k_eager = kc.clone()
+    assert torch.isfinite(eager.float()).all()
+    for b in range(1, batch):
+        assert torch.equal(eager[b], eager[0])
+    assert torch.equal(kc[:, 1], kc[:, 0])
+    out = torch.empty_like(x)
+    s = torch.cuda.Stream()
+    kc.copy_(k0); vc.copy_(v0)
+    with torch.cuda.stream(s):
+        dec.forward(x, out, kc, vc, -1, step_dev=step_dev)
+    s.synchronize()
+    kc.copy_(k0); vc.copy_(v0)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        dec.forward(x, out, kc, vc, -1, step_dev=step_dev)
+    kc.copy_(k0); vc.copy_(v0)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager) and torch.equal(kc, k_eager)
+    dec.close()
