@@ -203,6 +203,7 @@ public:
 
     // llama.cpp:322-398.  Returns the generated text; printRes(index, piece), index -1 = end of reply.
     std::vector<int> last_token_ids;
+    const Tokenizer &getTokenizer() const { return tokenizer; }
     std::string response(const std::vector<std::string> &input, CallBack printRes) override {
         const std::vector<int> history_ids = input.size() > 1 && !input[1].empty() ? tokenizer.Encode(input[1]) : std::vector<int>();
         const std::vector<int> cur_ids = tokenizer.Encode(input.empty() ? std::string() : input[0]);

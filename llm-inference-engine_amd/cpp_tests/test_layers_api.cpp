@@ -350,6 +350,47 @@ template <typename T> static void run(bool fp16) {
         const std::vector<int> second = static_cast<LlamaModel<T> *>(model.get())->last_token_ids;
         check_equal("LlamaModel deterministic tokens", second, first);
     }
+    {   // the same flow with a vocabulary file in the reference's binary format (tokenizer.h:138-167): the prompt goes through
+        // Encode (byte fallback + merges), every generated id through Decode
+        char tmpl[] = "/tmp/llmie_vocab_XXXXXX";
+        const int fd = mkstemp(tmpl);
+        if (fd < 0) throw std::runtime_error("mkstemp failed");
+        FILE *f = fdopen(fd, "wb");
+        auto wi = [&](int v) { std::fwrite(&v, 4, 1, f); };
+        auto wf = [&](float v) { std::fwrite(&v, 4, 1, f); };
+        std::vector<std::pair<std::string, float>> toks;
+        static const char *hexd = "0123456789ABCDEF";
+        for (int c = 0; c < 256; ++c) toks.push_back({std::string("<0x") + hexd[c >> 4] + hexd[c & 15] + ">", 0.f});
+        toks.push_back({"\xE2\x96\x81", -100.f});
+        for (char c = 'a'; c <= 'z'; ++c) toks.push_back({std::string(1, c), -200.f});
+        for (const char *w : {"he", "ll", "hell", "hello", "wo", "wor", "ld", "world", "\xE2\x96\x81hello", "\xE2\x96\x81world"})
+            toks.push_back({w, -static_cast<float>(toks.size() % 17) - 1.f});
+        wi(1); wi(0);  // version 1, empty key-value table
+        wi(static_cast<int>(toks.size()));
+        for (size_t i = 0; i < toks.size(); ++i) {
+            wi(static_cast<int>(toks[i].first.size()));
+            for (unsigned char c : toks[i].first) wi(c);
+            wi(static_cast<int>(i) + 3);
+            wf(toks[i].second);
+        }
+        std::fclose(f);
+        srand(42);
+        std::unique_ptr<BaseModel> model(llm::createDummyLLMModel<T>(tmpl));
+        LlamaModel<T> *lm = static_cast<LlamaModel<T> *>(model.get());
+        const std::vector<int> ids = lm->getTokenizer().Encode("hello world");
+        const bool enc_ok = lm->getTokenizer().loaded && ids.size() == 2 && lm->getTokenizer().Decode(ids) == " hello world";
+        std::string pieces;
+        const std::string reply = model->Response(model->MakeInput("", 0, "hello world"), [&](int index, const char *c) {
+            if (index >= 0) pieces += c;
+        });
+        std::string expect;
+        for (int id : lm->last_token_ids) expect += lm->getTokenizer().Decode({id});
+        const bool ok = enc_ok && reply == pieces && reply == expect && !lm->last_token_ids.empty();
+        std::printf(ok ? "LlamaModel chat flow with a vocabulary file passed (%zu prompt ids)\n"
+                       : "FAIL LlamaModel chat flow with a vocabulary file (%zu prompt ids)\n", ids.size());
+        if (!ok) ++g_failures;
+        std::remove(tmpl);
+    }
 }
 
 int main(int argc, char **) {
