@@ -15,6 +15,10 @@
 #include <omp.h>
 #endif
 
+void orc_set_num_threads(int n) {
+    if (n > 0) omp_set_num_threads(n);
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -186,6 +186,7 @@ void orc_self_decoder(const orc_llama_cfg *cfg, const orc_layer_weights *layers,
                       float *hidden, float *k_cache, float *v_cache,
                       int batch, int step, float *scratch);
 
+void orc_set_num_threads(int n); /* OpenMP team size used by the functions below (bench.py: the box's CPU share) */
 int orc_num_threads(void);
 
 #ifdef __cplusplus

@@ -39,6 +39,8 @@ def lib():
         _lib.orc_uniform_philox.restype = C.c_float
         _lib.orc_uniform_philox.argtypes = [C.c_uint32, C.c_uint32]
         _lib.orc_num_threads.restype = C.c_int
+        _lib.orc_set_num_threads.argtypes = [C.c_int]
+        _lib.orc_set_num_threads.restype = None
     return _lib
 
 
