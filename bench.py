@@ -120,32 +120,11 @@ def decode_bytes_per_step(cfg, batch, ctx, wbytes=2.0, kvbytes=2):
     return int(weights + kv)
 
 
-def host_cpu_share():
-    """CPUs this process may actually use: cgroup quota (cpu.max) and affinity mask, whichever is smaller.  A GPU box gives
-    a one-GPU job a share of the host (16 CPUs), not its 128 hardware threads: an OpenMP team of 128 on 16 CPUs spins on
-    its own barriers (measured 18x slower than a team sized to the share)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()  # cgroup v2
-        if quota != "max":
-            n = min(n, max(1, -(-int(quota) // int(period))))
-    except (OSError, ValueError):
-        try:  # cgroup v1
-            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if quota > 0 and period > 0:
-                n = min(n, max(1, -(-quota // period)))
-        except (OSError, ValueError):
-            pass
-    return max(1, n)
-
-
 def cpu_baseline(cfg, ctx, budget_s=25.0):
     """Times the oracle's decode step on the host cores (bounded sample: one layer + LM head)."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
-    orc.lib().orc_set_num_threads(host_cpu_share())
     rng = np.random.default_rng(0)
     nh, kvh, hs, I, V = cfg["head_num"], cfg["kv_head_num"], cfg["head_size"], cfg["inter_size"], cfg["vocab_size"]
     H, QKV = nh * hs, (nh + 2 * kvh) * hs

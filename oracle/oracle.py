@@ -31,6 +31,22 @@ def build(force=False):
 _lib = None
 
 
+def cpu_share():
+    """CPUs this process may use (cgroup quota and affinity mask): the OpenMP team is sized to it -- a team of all hardware
+    threads on a box that grants 16 CPUs spins on its own barriers (measured 18x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()))):
+        try:
+            quota, period = parse(open(path).read())
+            if quota not in ("max", "-1") and int(quota) > 0 and int(period) > 0:
+                n = min(n, max(1, -(-int(quota) // int(period))))
+            break
+        except (OSError, ValueError):
+            continue
+    return max(1, n)
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -41,6 +57,7 @@ def lib():
         _lib.orc_num_threads.restype = C.c_int
         _lib.orc_set_num_threads.argtypes = [C.c_int]
         _lib.orc_set_num_threads.restype = None
+        _lib.orc_set_num_threads(cpu_share())
     return _lib
 
 
