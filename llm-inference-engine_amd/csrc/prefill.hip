@@ -14,6 +14,8 @@
 //                                so every lane owns one query row's statistics (col = lane & 15) throughout.
 #include "llmie_internal.h"
 
+#include <cstdlib>
+
 namespace llmie {
 
 
@@ -27,10 +29,6 @@ __device__ __forceinline__ void locate_token(const int32_t *__restrict__ cum, in
 }
 
 // KV8: the caches are e4m3 bytes, stored = e4m3(x / scale) (same [L, bs, kvh, max_seq, hs] indexing in elements)
-__device__ __forceinline__ uint8_t e4m3_of(float x) {
-    x = fminf(fmaxf(x, -448.f), 448.f);
-    return static_cast<uint8_t>(__builtin_amdgcn_cvt_pk_fp8_f32(x, 0.f, 0, false) & 0xFF);
-}
 
 template <int HS, bool KV8>
 __global__ __launch_bounds__(256) void prefill_rope_append_kernel(half_t *__restrict__ qkv, const half_t *__restrict__ bias,
@@ -48,23 +46,35 @@ __global__ __launch_bounds__(256) void prefill_rope_append_kernel(half_t *__rest
     const int heads = head_num + 2 * kv_head_num;
     half_t *row = qkv + static_cast<size_t>(t) * heads * HS;
     const float2 *cs = rope + static_cast<size_t>(tpos) * HALF;
-    for (int i = threadIdx.x; i < heads * HALF; i += 256) {
-        const int h = i / HALF, d = i - h * HALF;
+    // one work item = 8 consecutive dims d .. d+7 of the first half of a head and their rotate-half partners d+HS/2 ..:
+    // two 16-byte loads, two 16-byte stores (the first version moved 2 bytes per access: 58 us per layer at 2048 tokens)
+    constexpr int GROUPS = HALF / 8;
+    for (int i = threadIdx.x; i < heads * GROUPS; i += 256) {
+        const int h = i / GROUPS, d = (i - h * GROUPS) * 8;
         half_t *src = row + static_cast<size_t>(h) * HS;
-        float x0 = to_f32(src[d]), x1 = to_f32(src[d + HALF]);
+        const half8_t lo = *reinterpret_cast<const half8_t *>(src + d), hi = *reinterpret_cast<const half8_t *>(src + d + HALF);
+        half8_t blo = {0, 0, 0, 0, 0, 0, 0, 0}, bhi = blo;
         if (bias) {
-            x0 += to_f32(bias[static_cast<size_t>(h) * HS + d]);
-            x1 += to_f32(bias[static_cast<size_t>(h) * HS + d + HALF]);
+            blo = *reinterpret_cast<const half8_t *>(bias + static_cast<size_t>(h) * HS + d);
+            bhi = *reinterpret_cast<const half8_t *>(bias + static_cast<size_t>(h) * HS + d + HALF);
         }
-        float o0 = x0, o1 = x1;
-        if (h < head_num + kv_head_num && d < (rotary_dim >> 1)) {
-            const float2 v = cs[d];
-            o0 = x0 * v.x - x1 * v.y;
-            o1 = x1 * v.x + x0 * v.y;
+        const bool rotate = h < head_num + kv_head_num;
+        half8_t olo, ohi;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x0 = to_f32(lo[e]) + to_f32(blo[e]), x1 = to_f32(hi[e]) + to_f32(bhi[e]);
+            float o0 = x0, o1 = x1;
+            if (rotate && d + e < (rotary_dim >> 1)) {
+                const float2 v = cs[d + e];
+                o0 = x0 * v.x - x1 * v.y;
+                o1 = x1 * v.x + x0 * v.y;
+            }
+            olo[e] = from_f32<half_t>(o0);
+            ohi[e] = from_f32<half_t>(o1);
         }
         if (h < head_num) {
-            src[d] = from_f32<half_t>(o0);
-            src[d + HALF] = from_f32<half_t>(o1);
+            *reinterpret_cast<half8_t *>(src + d) = olo;
+            *reinterpret_cast<half8_t *>(src + d + HALF) = ohi;
         } else {
             const bool is_k = h < head_num + kv_head_num;
             const int g = is_k ? h - head_num : h - head_num - kv_head_num;
@@ -73,26 +83,36 @@ __global__ __launch_bounds__(256) void prefill_rope_append_kernel(half_t *__rest
                 // quantise the fp16-rounded value (what the fp16 cache would hold), as the decode kernel does
                 uint8_t *dst = static_cast<uint8_t *>(is_k ? k_cache : v_cache) + off;
                 const float inv = is_k ? k_inv_scale : v_inv_scale;
-                dst[d] = e4m3_of(to_f32(from_f32<half_t>(o0)) * inv);
-                dst[d + HALF] = e4m3_of(to_f32(from_f32<half_t>(o1)) * inv);
+                uint2 plo, phi;
+                plo.x = pack4_e4m3(to_f32(olo[0]) * inv, to_f32(olo[1]) * inv, to_f32(olo[2]) * inv, to_f32(olo[3]) * inv);
+                plo.y = pack4_e4m3(to_f32(olo[4]) * inv, to_f32(olo[5]) * inv, to_f32(olo[6]) * inv, to_f32(olo[7]) * inv);
+                phi.x = pack4_e4m3(to_f32(ohi[0]) * inv, to_f32(ohi[1]) * inv, to_f32(ohi[2]) * inv, to_f32(ohi[3]) * inv);
+                phi.y = pack4_e4m3(to_f32(ohi[4]) * inv, to_f32(ohi[5]) * inv, to_f32(ohi[6]) * inv, to_f32(ohi[7]) * inv);
+                *reinterpret_cast<uint2 *>(dst + d) = plo;
+                *reinterpret_cast<uint2 *>(dst + d + HALF) = phi;
             } else {
                 half_t *dst = static_cast<half_t *>(is_k ? k_cache : v_cache) + off;
-                dst[d] = from_f32<half_t>(o0);
-                dst[d + HALF] = from_f32<half_t>(o1);
+                *reinterpret_cast<half8_t *>(dst + d) = olo;
+                *reinterpret_cast<half8_t *>(dst + d + HALF) = ohi;
             }
         }
     }
 }
 
-// grid: (q tiles of 64 rows over max_q_len, head_num, batch); block 256 = 4 waves x 16 query rows
-template <int HS, bool KV8>
-__global__ __launch_bounds__(256) void prefill_flash_kernel(const half_t *__restrict__ qkv, const void *__restrict__ k_cache,
+// grid: (q tiles of NW*16 rows over max_q_len, head_num, batch); block = NW waves x 16 query rows.  NW = 8: a staged 64-key K/V
+// tile (global -> LDS, two barriers: 80 of the 175 us of the 4-wave form at 2048 tokens) serves 128 query rows.
+template <int HS, bool KV8, int NW>
+__global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__restrict__ qkv, const void *__restrict__ k_cache,
                                                             const void *__restrict__ v_cache, half_t *__restrict__ out,
                                                             const int32_t *__restrict__ cum, const int32_t *__restrict__ hist,
                                                             int head_num, int kv_head_num, int max_seq_len, size_t layer_off,
                                                             float k_scale, float v_scale) {
     static_assert(HS == 128, "tuned for head_size 128");
-    constexpr int BQ = 64, BT = 64, VSTRIDE = HS + 4;  // V rows padded by 8 bytes (bank spread for the column gathers)
+    // V rows are 288 bytes (256 + 32): the PV operand is fetched with ds_read_b64_tr_b16 (gfx950 transposed LDS read: a 16-lane
+    // group reads a block of 4 keys x 16 head dims and every lane receives one column of it = 4 consecutive keys of its head
+    // dim), whose 16 lanes address 4 rows x 4 eight-byte pieces -- rows 32 bytes apart modulo 256 keep a 32-lane half
+    // conflict-free.  (The first version gathered the column with 8 scalar 2-byte LDS reads per fragment: 63 of 175 us.)
+    constexpr int BQ = NW * 16, BT = 64, VSTRIDE = HS + 16, NTHR = NW * 64;
     __shared__ __attribute__((aligned(16))) half_t Ks[BT * HS];
     __shared__ __attribute__((aligned(16))) half_t Vs[BT * VSTRIDE];
     const int b = blockIdx.z, h = blockIdx.y;
@@ -130,8 +150,8 @@ __global__ __launch_bounds__(256) void prefill_flash_kernel(const half_t *__rest
         __syncthreads();  // previous tile consumed
         // stage K (swizzled 16-byte chunks) and V (row-major, padded) tiles: 64 rows x 16 chunks each, 4 per thread
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int id = tid + 256 * i, row = id >> 4, ch = id & 15;
+        for (int i = 0; i < 1024 / NTHR; ++i) {
+            const int id = tid + NTHR * i, row = id >> 4, ch = id & 15;
             const int t = min(t0 + row, ctx - 1);
             half8_t kvv, vvv;
             if constexpr (KV8) {
@@ -153,10 +173,12 @@ __global__ __launch_bounds__(256) void prefill_flash_kernel(const half_t *__rest
                 vvv = *reinterpret_cast<const half8_t *>(vc + static_cast<size_t>(t) * HS + ch * 8);
             }
             *reinterpret_cast<half8_t *>(Ks + row * HS + ((ch ^ (row & 15)) << 3)) = kvv;
-            *reinterpret_cast<half4_t *>(Vs + row * VSTRIDE + ch * 8) = half4_t{vvv[0], vvv[1], vvv[2], vvv[3]};
-            *reinterpret_cast<half4_t *>(Vs + row * VSTRIDE + ch * 8 + 4) = half4_t{vvv[4], vvv[5], vvv[6], vvv[7]};
+            *reinterpret_cast<half8_t *>(Vs + row * VSTRIDE + ch * 8) = vvv;
         }
         __syncthreads();
+        // key tiles entirely in the future of this wave's 16 query rows are skipped by the whole wave (it still takes part in
+        // the staging and the barriers above)
+        if (t0 > history + q0 + wave * 16 + 15) continue;
         // ---- S^T = K . Q^T : 4 key tiles of 16, 4 k-steps over the head dim ----
         floatx4 sacc[4];
 #pragma unroll
@@ -202,16 +224,24 @@ __global__ __launch_bounds__(256) void prefill_flash_kernel(const half_t *__rest
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) o[dt] *= alpha;
         // ---- O^T += V^T . P^T : A fragment = V[t(q,j)][d = 16 dt + r] gathered down a column ----
+        // lane (r, q) of its 16-lane group supplies the address of block row (r >> 2), columns 4 (r & 3) .. +3, and receives
+        // column r of the block's 4 rows; all 16 transposed reads of a 32-key step are issued before its 8 MFMAs
+        typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+        typedef __attribute__((address_space(3))) fp16x4_t *lds_fp16x4_ptr;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
+            const half_t *blk = Vs + (32 * c + 4 * q + (r >> 2)) * VSTRIDE + 4 * (r & 3);
+            fp16x4_t lo[8], hi[8];
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) {
-                half8_t vf;
+                lo[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4_ptr)(blk + dt * 16));
+                hi[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4_ptr)(blk + 16 * VSTRIDE + dt * 16));
+            }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int trow = 32 * c + (j >> 2) * 16 + 4 * q + (j & 3);
-                    vf[j] = Vs[trow * VSTRIDE + dt * 16 + r];
-                }
+            for (int dt = 0; dt < 8; ++dt) {
+                const half8_t vf = {static_cast<half_t>(lo[dt][0]), static_cast<half_t>(lo[dt][1]), static_cast<half_t>(lo[dt][2]),
+                                    static_cast<half_t>(lo[dt][3]), static_cast<half_t>(hi[dt][0]), static_cast<half_t>(hi[dt][1]),
+                                    static_cast<half_t>(hi[dt][2]), static_cast<half_t>(hi[dt][3])};
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[c], o[dt], 0, 0, 0);
             }
         }
@@ -237,20 +267,29 @@ int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, void *k_cache, vo
         return LLMIE_ERR_UNSUPPORTED;
     }
     const size_t layer_off = static_cast<size_t>(layer) * batch * kv_head_num * max_seq_len * head_size;
-    dim3 grid((max_q_len + 63) / 64, head_num, batch);
-    if (kv_fp8) {
+    static const int nw = getenv("LLMIE_PF_NW") ? atoi(getenv("LLMIE_PF_NW")) : 8;  // waves per workgroup (x 16 query rows)
+    const int bq = (nw == 4 ? 4 : 8) * 16;
+    dim3 grid((max_q_len + bq - 1) / bq, head_num, batch);
+    const float ks = kv_fp8 ? k_scale : 1.f, vs = kv_fp8 ? v_scale : 1.f;
+    if (kv_fp8)
         prefill_rope_append_kernel<128, true><<<num_tokens, 256, 0, st>>>(qkv, qkv_bias, k_cache, v_cache, cum_seqlens, history_len,
                                                                           rope, batch, head_num, kv_head_num, max_seq_len,
-                                                                          rotary_dim, layer_off, 1.0f / k_scale, 1.0f / v_scale);
-        prefill_flash_kernel<128, true><<<grid, 256, 0, st>>>(qkv, k_cache, v_cache, out, cum_seqlens, history_len, head_num,
-                                                              kv_head_num, max_seq_len, layer_off, k_scale, v_scale);
-    } else {
+                                                                          rotary_dim, layer_off, 1.0f / ks, 1.0f / vs);
+    else
         prefill_rope_append_kernel<128, false><<<num_tokens, 256, 0, st>>>(qkv, qkv_bias, k_cache, v_cache, cum_seqlens, history_len,
                                                                            rope, batch, head_num, kv_head_num, max_seq_len,
                                                                            rotary_dim, layer_off, 1.f, 1.f);
-        prefill_flash_kernel<128, false><<<grid, 256, 0, st>>>(qkv, k_cache, v_cache, out, cum_seqlens, history_len, head_num,
-                                                               kv_head_num, max_seq_len, layer_off, 1.f, 1.f);
+#define LLMIE_FLASH(KV8_, NW_)                                                                                                  \
+    prefill_flash_kernel<128, KV8_, NW_><<<grid, NW_ * 64, 0, st>>>(qkv, k_cache, v_cache, out, cum_seqlens, history_len, head_num, \
+                                                                    kv_head_num, max_seq_len, layer_off, ks, vs)
+    if (kv_fp8) {
+        if (nw == 4) LLMIE_FLASH(true, 4);
+        else LLMIE_FLASH(true, 8);
+    } else {
+        if (nw == 4) LLMIE_FLASH(false, 4);
+        else LLMIE_FLASH(false, 8);
     }
+#undef LLMIE_FLASH
     return launch_status("prefill_attention");
 }
 

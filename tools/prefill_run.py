@@ -19,7 +19,13 @@ hid = torch.randn((T, H), device="cuda").half()
 out = torch.empty_like(hid)
 lens = torch.full((b,), s, dtype=torch.int32, device="cuda")
 hist = torch.zeros(b, dtype=torch.int32, device="cuda")
-for _ in range(3):
+for _ in range(2):
     dec.prefill(hid, out, kc, vc, lens, hist, s)
 torch.cuda.synchronize()
-print("done")
+P = 4
+dec.profile_begin(P * (cfg["num_layers"] * 12 + 8))
+for _ in range(P):
+    dec.prefill(hid, out, kc, vc, lens, hist, s)
+for op, (ms, n) in dec.profile_end().items():
+    if n:
+        print("%-16s %9.1f us/launch  x%3d per pass" % (op, ms / n * 1e3, n // P))
