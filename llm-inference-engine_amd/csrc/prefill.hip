@@ -113,8 +113,11 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
     // dim), whose 16 lanes address 4 rows x 4 eight-byte pieces -- rows 32 bytes apart modulo 256 keep a 32-lane half
     // conflict-free.  (The first version gathered the column with 8 scalar 2-byte LDS reads per fragment: 63 of 175 us.)
     constexpr int BQ = NW * 16, BT = 64, VSTRIDE = HS + 16, NTHR = NW * 64;
-    __shared__ __attribute__((aligned(16))) half_t Ks[BT * HS];
-    __shared__ __attribute__((aligned(16))) half_t Vs[BT * VSTRIDE];
+    // two K/V tile buffers (2 x 34 KiB): tile t+1 is written while tile t is multiplied, ONE barrier per iteration; its
+    // global loads are issued a full iteration earlier (registers), pinned ahead of the MFMAs with a scheduling barrier --
+    // at 2 resident workgroups per CU nothing else hides an L2/HBM round trip
+    __shared__ __attribute__((aligned(16))) half_t Ksb[2][BT * HS];
+    __shared__ __attribute__((aligned(16))) half_t Vsb[2][BT * VSTRIDE];
     const int b = blockIdx.z, h = blockIdx.y;
     const int len = cum[b + 1] - cum[b], history = hist[b];
     const int q0 = blockIdx.x * BQ;
@@ -146,18 +149,32 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
     float m_run = -INFINITY, l_run = 0.f;
 
     const int t_hi = min(ctx, history + min(q0 + BQ, len));  // keys needed by any row of this q tile
-    for (int t0 = 0; t0 < t_hi; t0 += BT) {
-        __syncthreads();  // previous tile consumed
-        // stage K (swizzled 16-byte chunks) and V (row-major, padded) tiles: 64 rows x 16 chunks each, 4 per thread
+    constexpr int NCH = 1024 / NTHR;  // 16-byte chunks of each tile per thread
+    half8_t kreg[NCH], vreg[NCH];
+    uint2 kreg8[NCH], vreg8[NCH];
+    (void)kreg; (void)vreg; (void)kreg8; (void)vreg8;
+    auto fetch_tile = [&](int t0) {  // global -> registers
 #pragma unroll
-        for (int i = 0; i < 1024 / NTHR; ++i) {
+        for (int i = 0; i < NCH; ++i) {
             const int id = tid + NTHR * i, row = id >> 4, ch = id & 15;
             const int t = min(t0 + row, ctx - 1);
+            if constexpr (KV8) {
+                kreg8[i] = *reinterpret_cast<const uint2 *>(kc8 + static_cast<size_t>(t) * HS + ch * 8);
+                vreg8[i] = *reinterpret_cast<const uint2 *>(vc8 + static_cast<size_t>(t) * HS + ch * 8);
+            } else {
+                kreg[i] = *reinterpret_cast<const half8_t *>(kc + static_cast<size_t>(t) * HS + ch * 8);
+                vreg[i] = *reinterpret_cast<const half8_t *>(vc + static_cast<size_t>(t) * HS + ch * 8);
+            }
+        }
+    };
+    auto publish_tile = [&](int buf) {  // registers -> LDS: K in swizzled 16-byte chunks, V row-major with padded rows
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int id = tid + NTHR * i, row = id >> 4, ch = id & 15;
             half8_t kvv, vvv;
             if constexpr (KV8) {
                 // 8 e4m3 bytes -> 8 halves (x scale): the tiles in LDS are fp16 either way
-                const uint2 kb = *reinterpret_cast<const uint2 *>(kc8 + static_cast<size_t>(t) * HS + ch * 8);
-                const uint2 vb = *reinterpret_cast<const uint2 *>(vc8 + static_cast<size_t>(t) * HS + ch * 8);
+                const uint2 kb = kreg8[i], vb = vreg8[i];
                 const half2_t k0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(kb.x), k_scale, false);
                 const half2_t k1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(kb.x), k_scale, true);
                 const half2_t k2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(kb.y), k_scale, false);
@@ -169,13 +186,24 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
                 kvv = half8_t{k0[0], k0[1], k1[0], k1[1], k2[0], k2[1], k3[0], k3[1]};
                 vvv = half8_t{v0[0], v0[1], v1[0], v1[1], v2[0], v2[1], v3[0], v3[1]};
             } else {
-                kvv = *reinterpret_cast<const half8_t *>(kc + static_cast<size_t>(t) * HS + ch * 8);
-                vvv = *reinterpret_cast<const half8_t *>(vc + static_cast<size_t>(t) * HS + ch * 8);
+                kvv = kreg[i];
+                vvv = vreg[i];
             }
-            *reinterpret_cast<half8_t *>(Ks + row * HS + ((ch ^ (row & 15)) << 3)) = kvv;
-            *reinterpret_cast<half8_t *>(Vs + row * VSTRIDE + ch * 8) = vvv;
+            *reinterpret_cast<half8_t *>(Ksb[buf] + row * HS + ((ch ^ (row & 15)) << 3)) = kvv;
+            *reinterpret_cast<half8_t *>(Vsb[buf] + row * VSTRIDE + ch * 8) = vvv;
         }
-        __syncthreads();
+    };
+    fetch_tile(0);
+    publish_tile(0);
+    if (BT < t_hi) fetch_tile(BT);
+    for (int t0 = 0, it = 0; t0 < t_hi; t0 += BT, ++it) {
+        const half_t *Ks = Ksb[it & 1], *Vs = Vsb[it & 1];
+        __syncthreads();  // tile `it` published by every thread; every wave done with tile it-1 (the other buffer)
+        if (t0 + BT < t_hi) {
+            publish_tile((it + 1) & 1);                        // tile it+1: registers (fetched last iteration) -> other buffer
+            if (t0 + 2 * BT < t_hi) fetch_tile(t0 + 2 * BT);   // tile it+2: in flight under this iteration's MFMAs
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the loads above the compute below
         // key tiles entirely in the future of this wave's 16 query rows are skipped by the whole wave (it still takes part in
         // the staging and the barriers above)
         if (t0 > history + q0 + wave * 16 + 15) continue;
