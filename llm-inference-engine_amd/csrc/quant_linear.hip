@@ -146,6 +146,26 @@ int linear_wq(int wbits, const half_t *x, const void *wq, const half_t *scale, h
         const GemvArgs a{x, wq, y, K, N, bias, residual, gamma, pre_bias, eps, epi, gamma ? 1 : 0, scale, group};
         if (gemv_q_launch(wbits, M, a, st)) return launch_status("linear_wq");
     }
+    if (aligned && wbits == 4) {
+        // int4 has no MFMA form yet: batches beyond the GEMV's register budget run as row chunks of the largest eligible
+        // size (the weights are streamed once per chunk -- correct for any batch, bandwidth-efficient only for small ones)
+        int mc = 8;
+        while (mc > 0 && !ksplit_eligible(mc, K, 4)) --mc;
+        if (mc > 0) {
+            const int out_n = epi == EPI_SWIGLU ? N / 2 : N;
+            for (int m0 = 0; m0 < M; m0 += mc) {
+                const int m = M - m0 < mc ? M - m0 : mc;
+                const GemvArgs a{x + static_cast<size_t>(m0) * K, wq, y + static_cast<size_t>(m0) * out_n, K, N, bias,
+                                 residual ? residual + static_cast<size_t>(m0) * N : nullptr, gamma, pre_bias, eps, epi, gamma ? 1 : 0,
+                                 scale, group};
+                if (!gemv_q_launch(4, m, a, st)) {
+                    set_error("linear_wq: no int4 GEMV instantiation for M=%d K=%d", m, K);
+                    return LLMIE_ERR_UNSUPPORTED;
+                }
+            }
+            return launch_status("linear_wq(int4, row chunks)");
+        }
+    }
     if (gamma) {
         set_error("linear_wq: fused norm only on the GEMV path (M=%d K=%d bits=%d)", M, K, wbits);
         return LLMIE_ERR_UNSUPPORTED;
