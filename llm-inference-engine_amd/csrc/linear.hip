@@ -179,11 +179,13 @@ static float *splitk_scratch(size_t floats) {
     static float *buf = nullptr;
     static size_t cap = 0;
     if (floats > cap) {
-        if (buf) (void)hipFree(buf);
-        buf = nullptr;
-        cap = 0;
-        if (hipMalloc(reinterpret_cast<void **>(&buf), floats * sizeof(float)) != hipSuccess) return nullptr;
-        cap = floats;
+        // grow-only and geometric, and the outgrown buffer is NOT freed: a hipGraph captured earlier may still replay
+        // launches that point into it (doubling keeps the retained total below twice the final size)
+        const size_t want = floats > 2 * cap ? floats : 2 * cap;
+        float *bigger = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&bigger), want * sizeof(float)) != hipSuccess) return nullptr;
+        buf = bigger;
+        cap = want;
     }
     return buf;
 }
