@@ -395,6 +395,7 @@ def main():
         torch.cuda.empty_cache()
         q4 = quantize_layers(torch, llmie, weights["layers"], "int4")
         record("decode_int4_b1_ctx2048", "int4", q4, 1, 2048, 0.5 + 2.0 / 128)
+        record("decode_int4_b32_ctx128", "int4", q4, 32, 128, 0.5 + 2.0 / 128)
         del q4
         torch.cuda.empty_cache()
         q8f = quantize_layers(torch, llmie, weights["layers"], "fp8")   # BASELINE configs[4]: fp8 batch sweep at ctx 512

@@ -377,7 +377,7 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
         return LLMIE_OK;
     }
 
-    // ---- fused batch decode path (8 < batch <= 128; fp16, int8 or fp8 weights): 8 launches per layer (+ the attention
+    // ---- fused batch decode path (8 < batch <= 128; fp16, int8, int4 (<= 64) or fp8 weights): 8 launches per layer (+ the attention
     // merge when the context spans several chunks) instead of 11-12.  Every projection is a split-K MFMA launch that
     // leaves fp32 partial slabs; the consumer of each slab does the reduction:
     //   qkv slabs            -> read directly by the attention launch (q rows, new k/v rows; + scale, bias, RoPE, append)
@@ -387,7 +387,8 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
     // fp8: activations enter every projection as per-token e4m3; the row kernel emits them directly for the qkv and
     // gate_up inputs, the attention and SwiGLU outputs take a quantize_rows launch each (10 launches per layer).
     static const int batch_fused_off = getenv("LLMIE_NO_FUSED_BATCH") ? 1 : 0;
-    if (!batch_fused_off && c.dtype == LLMIE_F16 && (wbits == 16 || wbits == 8 || fp8) && hs_ok && rep_ok && batch <= 128 &&
+    const bool int4_ok = wbits == 4 && c.int4_group == 128 && batch <= 64;  // int4 MFMA form: group-128 scales, 64 rows per pass
+    if (!batch_fused_off && c.dtype == LLMIE_F16 && (wbits == 16 || wbits == 8 || int4_ok || fp8) && hs_ok && rep_ok && batch <= 128 &&
         H % 256 == 0 && I % 256 == 0 && H >= 512 && I >= 512 && splitk_rownorm_eligible(H)) {
         hipStream_t st = as_stream(stream);
         half_t *hh = static_cast<half_t *>(h), *resid = reinterpret_cast<half_t *>(dec->resid);
@@ -404,6 +405,8 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
             if (fp8) return SlabScale{nullptr, static_cast<const float *>(m.scale), xs};
             return SlabScale{wbits == 8 ? static_cast<const half_t *>(m.scale) : nullptr, nullptr, nullptr};
         };
+        // int4: the group scales are applied inside the split-K kernel (the slabs hold scaled values)
+        auto gs_of = [&](const llmie_matrix &m) { return wbits == 4 ? static_cast<const half_t *>(m.scale) : nullptr; };
         // self_decoder.cpp:77 (first layer only: later ones get it from the previous layer's down-projection epilogue)
         TIMED(LLMIE_OP_ATTN_NORM, llmie_rmsnorm(h, dec->resid, dec->layers[0].attn_norm_gamma, c.rms_eps, batch, H, dt, stream));
         if (fp8) TIMED(LLMIE_OP_ATTN_NORM, quantize_rows_fp8(hh, xqA, xsA, batch, H, st));
@@ -412,23 +415,23 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
             const bool last = l + 1 == c.num_layers;
             const void *xin = fp8 ? static_cast<const void *>(xqA) : hh;
             SplitKSlabs sk;
-            TIMED(LLMIE_OP_QKV_GEMM, linear_splitk_partial(fmt, xin, w.qkv.data, batch, H, QKV, st, &sk));
+            TIMED(LLMIE_OP_QKV_GEMM, linear_splitk_partial(fmt, xin, w.qkv.data, batch, H, QKV, st, &sk, gs_of(w.qkv)));
             const SlabScale qsc = scale_of(w.qkv, xsA);
             TIMED(LLMIE_OP_MHA, decoder_mha_rope(nullptr, w.qkv.bias, k_cache, v_cache, dec->mha, l, batch, c.head_num,
                                                  c.kv_head_num, c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws,
                                                  dec->attn_ws_bytes, dec->rope_table, c.rotary_dim, nullptr, dt, st, &sk, &qsc, kv8,
                                                  k_scale, v_scale));
             if (fp8) TIMED(LLMIE_OP_O_GEMM, quantize_rows_fp8(mha, xqB, xsB, batch, H, st));
-            TIMED(LLMIE_OP_O_GEMM, linear_splitk_partial(fmt, fp8 ? static_cast<const void *>(xqB) : mha, w.o.data, batch, H, H, st, &sk));
+            TIMED(LLMIE_OP_O_GEMM, linear_splitk_partial(fmt, fp8 ? static_cast<const void *>(xqB) : mha, w.o.data, batch, H, H, st, &sk, gs_of(w.o)));
             // self_decoder.cpp:92  h += resid; resid = h; h += o.bias; h = rmsnorm(h, ffn_gamma)
             TIMED(LLMIE_OP_FFN_NORM, splitk_rownorm(sk, scale_of(w.o, xsB), static_cast<const half_t *>(w.o.bias), resid,
                                                     static_cast<const half_t *>(w.ffn_norm_gamma), c.rms_eps,
                                                     fp8 ? nullptr : hh, xqA, xsA, st));
             // ffn.cpp:105-122  act = silu(h.Wg^T) * (h.Wu^T)
-            TIMED(LLMIE_OP_GATE_UP_SWIGLU, linear_splitk_partial(fmt, xin, w.gate_up.data, batch, H, 2 * I, st, &sk));
+            TIMED(LLMIE_OP_GATE_UP_SWIGLU, linear_splitk_partial(fmt, xin, w.gate_up.data, batch, H, 2 * I, st, &sk, gs_of(w.gate_up)));
             TIMED(LLMIE_OP_GATE_UP_SWIGLU, splitk_finalize(sk, scale_of(w.gate_up, xsA), act, EPI_SWIGLU_, nullptr, nullptr, st));
             if (fp8) TIMED(LLMIE_OP_DOWN_GEMM, quantize_rows_fp8(act, xqC, xsC, batch, I, st));
-            TIMED(LLMIE_OP_DOWN_GEMM, linear_splitk_partial(fmt, fp8 ? static_cast<const void *>(xqC) : act, w.down.data, batch, I, H, st, &sk));
+            TIMED(LLMIE_OP_DOWN_GEMM, linear_splitk_partial(fmt, fp8 ? static_cast<const void *>(xqC) : act, w.down.data, batch, I, H, st, &sk, gs_of(w.down)));
             // ffn.cpp:132 + self_decoder.cpp:111 h = act.Wd^T + resid, then the next layer's resid = h; h = rmsnorm(h)
             const void *next_gamma = last ? nullptr : dec->layers[l + 1].attn_norm_gamma;
             TIMED(LLMIE_OP_ATTN_NORM, splitk_rownorm(sk, scale_of(w.down, xsC), nullptr, resid, static_cast<const half_t *>(next_gamma),

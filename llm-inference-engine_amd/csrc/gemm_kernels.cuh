@@ -638,10 +638,16 @@ __device__ __forceinline__ half8_t dequant_i8x8(unsigned int w0, unsigned int w1
 
 // FP8 (WBITS == 8): e4m3 weights AND e4m3 activations (x is [M,K] bytes, quantised per token by the producer), fed to
 // v_mfma_f32_16x16x32_fp8_fp8 without any conversion; the scales (wscale[n] * xscale[m]) are applied by the slab consumer.
+// int4 (WBITS == 4, group size 128): a 16-byte load = 32 weights = 4 MFMA k-steps of one row; a sub-block (512 k) spans 4
+// scale groups, one per fragment: each group's products are accumulated from zero on the MFMA and folded into the running
+// total with the fp32 scale of (row, group) -- exact group scaling, 8 fp32 FMAs per output tile instead of a multiply per
+// weight.  Nibbles come out of the word in the order (0,4,1,5,2,6,3,7): the activation chunks are permuted to match when
+// they are staged.  The slabs hold fully scaled values (no consumer-side scale).  K % 32 == 0; a ragged last sub-block
+// multiplies clamped (in-bounds) weight bytes with zeroed activations.
 template <int MT, int WBITS, bool FP8 = false>
 __global__ __launch_bounds__(256) void skinny_splitk_kernel(const void *__restrict__ xv, const void *__restrict__ W,
                                                             float *__restrict__ slab, int M, int K, int N, int KS,
-                                                            int blocks_per_slice) {
+                                                            int blocks_per_slice, const half_t *__restrict__ gscale) {
     // One sub-block = 4 weight loads per lane: fp16 BK = 128 (4 steps of 32), int8 / fp8 BK = 256 (4 steps of 64).
     // The activation tile [16*MT rows][BK] of the sub-block is staged in LDS (coalesced 16-byte loads, chunks
     // XOR-swizzled with the row so a fragment read -- 16 rows x one chunk column -- is conflict-free) and shared by
@@ -649,7 +655,7 @@ __global__ __launch_bounds__(256) void skinny_splitk_kernel(const void *__restri
     // bound the first versions of this kernel at ~90 cycles per wave-load).  Weight fragments go HBM -> VGPR with
     // the next sub-block's loads in flight while the current one is multiplied; x tiles are double buffered.
     static_assert(!FP8 || WBITS == 8, "fp8 is an 8-bit format");
-    constexpr int KSTEP = (WBITS == 16) ? 32 : 64;
+    constexpr int KSTEP = (WBITS == 16) ? 32 : (WBITS == 4 ? 128 : 64);
     constexpr int BK = 4 * KSTEP;
     constexpr int ROWS = 16 * MT;
     constexpr int XB = FP8 ? 1 : 2;                // bytes per activation element
@@ -677,8 +683,9 @@ __global__ __launch_bounds__(256) void skinny_splitk_kernel(const void *__restri
     size_t wrow_off[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) wrow_off[u] = static_cast<size_t>(min(n0 + 4 * u + q, N - 1)) * row_bytes;
-    const int nblocks = K / BK;
+    const int nblocks = (K + BK - 1) / BK;  // int4: the last sub-block may be ragged
     const int b_begin = ks * blocks_per_slice, b_end = min(nblocks, b_begin + blocks_per_slice);
+    const int sgroups = K / 128;            // int4: scales per weight row
 
     // weight fragments: ring of 4 sub-blocks (16 loads in flight per lane), refilled as soon as a slot is consumed
 #ifndef LLMIE_SK_RING_MIN
@@ -689,10 +696,24 @@ __global__ __launch_bounds__(256) void skinny_splitk_kernel(const void *__restri
     constexpr int R = G >= 4 ? 4 : (G > LLMIE_SK_RING_MIN ? G : LLMIE_SK_RING_MIN);
     constexpr int U = G > R ? G : R;     // main-loop unroll: ring slot (i % R) and group slot (i % G) both compile-time
     uint4_t a[R][4];
+    uint2 gsc[WBITS == 4 ? R : 1][4];  // int4: scales of D rows n0 + 4q + e for the sub-block's 4 groups
     uint4_t xr[XCH];
-    auto load_a = [&](int blk, uint4_t(&dst)[4]) {
+    auto load_a = [&](int blk, uint4_t(&dst)[4], uint2(&sc)[4]) {
+        if constexpr (WBITS == 4) {
+            // chunk r of the sub-block may lie past the row end in the last one: clamp into the row (its activations are zero)
+            const size_t off = min(static_cast<size_t>(blk) * 256 + 16 * r, row_bytes - 16) - 16 * r;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) dst[u] = load_nt(reinterpret_cast<const uint4_t *>(wp + wrow_off[u] + static_cast<size_t>(blk) * 256));
+            for (int u = 0; u < 4; ++u) dst[u] = load_nt(reinterpret_cast<const uint4_t *>(wp + wrow_off[u] + off));
+            const int g0 = min(blk * 4, sgroups - 4);  // 4 consecutive groups, clamped in-bounds (sgroups >= 4)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {  // K % 256 == 0 -> sgroups and g0 even -> 4-byte aligned pairs
+                const unsigned int *sp = reinterpret_cast<const unsigned int *>(gscale + static_cast<size_t>(min(n0 + 4 * q + e, N - 1)) * sgroups + g0);
+                sc[e] = uint2{sp[0], sp[1]};
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dst[u] = load_nt(reinterpret_cast<const uint4_t *>(wp + wrow_off[u] + static_cast<size_t>(blk) * 256));
+        }
     };
     unsigned char *wmine = &wsm[wave][0];
     // registers (row-contiguous image) -> LDS -> MFMA fragments; same-wave LDS ops execute in order, the fences only
@@ -718,7 +739,9 @@ __global__ __launch_bounds__(256) void skinny_splitk_kernel(const void *__restri
             const int id = min(tid + 256 * i, GCH - 1);
             const int g = id / (ROWS * CPR), rem = id - g * (ROWS * CPR), row = rem / CPR, ch = rem - row * CPR;
             const int blk = min(blk0 + g, last_blk);
-            xr[i] = *reinterpret_cast<const uint4_t *>(x + static_cast<size_t>(min(row, M - 1)) * x_row_bytes + static_cast<size_t>(blk) * RB + ch * 16);
+            const size_t koff = static_cast<size_t>(blk) * RB + ch * 16;  // byte offset inside the activation row
+            xr[i] = *reinterpret_cast<const uint4_t *>(x + static_cast<size_t>(min(row, M - 1)) * x_row_bytes + min(koff, x_row_bytes - 16));
+            if (WBITS == 4 && koff >= x_row_bytes) xr[i] = uint4_t{0u, 0u, 0u, 0u};  // past K in the ragged last sub-block
         }
     };
     auto store_xg = [&]() {
@@ -727,7 +750,12 @@ __global__ __launch_bounds__(256) void skinny_splitk_kernel(const void *__restri
             const int id = tid + 256 * i;
             if (id < GCH) {
                 const int g = id / (ROWS * CPR), rem = id - g * (ROWS * CPR), row = rem / CPR, ch = rem - row * CPR;
-                *reinterpret_cast<uint4_t *>(&xs[g][row * RB + ((ch ^ (row & 15)) << 4)]) = xr[i];
+                uint4_t v = xr[i];
+                if constexpr (WBITS == 4) {  // k order of the de-quantised nibbles: (0,4,1,5,2,6,3,7)
+                    const half8_t h = __builtin_bit_cast(half8_t, v);
+                    v = __builtin_bit_cast(uint4_t, half8_t{h[0], h[4], h[1], h[5], h[2], h[6], h[3], h[7]});
+                }
+                *reinterpret_cast<uint4_t *>(&xs[g][row * RB + ((ch ^ (row & 15)) << 4)]) = v;
             }
         }
     };
@@ -735,10 +763,46 @@ __global__ __launch_bounds__(256) void skinny_splitk_kernel(const void *__restri
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](const uint4_t(&ab)[4], int buf) {
+    auto compute = [&](const uint4_t(&ab)[4], const uint2(&sc)[4], int buf, int blk) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if constexpr (WBITS == 16) {
+            if constexpr (WBITS == 4) {
+                // fragment u = 32 weights of row r in group (4 blk + u): word s -> MFMA k-step s
+                floatx4 part[MT];
+#pragma unroll
+                for (int j = 0; j < MT; ++j) part[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+                const half2_t off8 = {static_cast<half_t>(1032.f), static_cast<half_t>(1032.f)};
+                const half2_t sixteenth = {static_cast<half_t>(0.0625f), static_cast<half_t>(0.0625f)};
+                const half2_t off72 = {static_cast<half_t>(72.f), static_cast<half_t>(72.f)};
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const unsigned int w0 = ab[u][st], w8 = w0 >> 8;
+                    const half2_t h0 = as_half2((w0 & 0x000F000Fu) | 0x64006400u) - off8;                    // n0, n4
+                    const half2_t h1 = as_half2((w0 & 0x00F000F0u) | 0x64006400u) * sixteenth - off72;      // n1, n5
+                    const half2_t h2 = as_half2((w8 & 0x000F000Fu) | 0x64006400u) - off8;                    // n2, n6
+                    const half2_t h3 = as_half2((w8 & 0x00F000F0u) | 0x64006400u) * sixteenth - off72;      // n3, n7
+                    const half8_t af = {h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
+#pragma unroll
+                    for (int j = 0; j < MT; ++j) {
+                        const int row = 16 * j + r, ch = (u * 4 + q) * 4 + st;
+                        const half8_t bf = *reinterpret_cast<const half8_t *>(&xs[buf][row * RB + ((ch ^ (row & 15)) << 4)]);
+                        part[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, part[j], 0, 0, 0);
+                    }
+                }
+                // D rows n0 + 4q + e: scale of (row, group); groups clamped at the matrix end were multiplied with zeros
+                const int gi = blk * 4 + u - min(blk * 4, sgroups - 4);  // position inside the 4 loaded scales (0..3, or past)
+                float sv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const half2_t lo = as_half2(sc[e].x), hi = as_half2(sc[e].y);
+                    const half_t hsel = gi == 0 ? lo[0] : (gi == 1 ? lo[1] : (gi == 2 ? hi[0] : hi[1]));
+                    sv[e] = gi < 4 ? to_f32(hsel) : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(part[j][e], sv[e], acc[j][e]);
+            } else if constexpr (WBITS == 16) {
                 const half8_t af = __builtin_bit_cast(half8_t, ab[u]);
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {
@@ -776,7 +840,7 @@ __global__ __launch_bounds__(256) void skinny_splitk_kernel(const void *__restri
     if (nb > 0) load_xg(b_begin, b_end - 1);  // activations first (L2), then the weight ring (HBM)
 #pragma unroll
     for (int i = 0; i < R; ++i)
-        if (i < nb) load_a(b_begin + i, a[i]);
+        if (i < nb) load_a(b_begin + i, a[i], gsc[WBITS == 4 ? i : 0]);
     static_assert(U % R == 0 && U % G == 0, "unroll vs ring depth / group size");
     for (int u0 = 0; u0 < nb; u0 += U) {
 #pragma unroll
@@ -790,9 +854,12 @@ __global__ __launch_bounds__(256) void skinny_splitk_kernel(const void *__restri
                     if (b + G < nb) load_xg(b_begin + b + G, b_end - 1);
                 }
                 uint4_t frag[4];
+                uint2 scur[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) scur[e] = gsc[WBITS == 4 ? i % R : 0][e];
                 transpose_w(a[i % R], frag);
-                if (b + R < nb) load_a(b_begin + b + R, a[i % R]);  // ring slot free again
-                compute(frag, i % G);
+                if (b + R < nb) load_a(b_begin + b + R, a[i % R], gsc[WBITS == 4 ? i % R : 0]);  // ring slot free again
+                compute(frag, scur, i % G, b_begin + b);
             }
         }
     }

@@ -193,20 +193,27 @@ static float *splitk_scratch(size_t floats) {
 // split-K skinny MFMA path, first half: partial products of one pass (8 < M <= 128) into the library's fp32 slabs
 // [KS][M][N].  The slabs stay valid until the next split-K launch on the stream; the consumer (finalize kernel,
 // splitk_rownorm, or the decode attention reading q/k/v straight from the slabs) must be enqueued before it.
-int linear_splitk_partial(int wbits, const void *x, const void *W, int M, int K, int N, hipStream_t st, SplitKSlabs *out) {
-    // wbits: 16 = fp16 weights, 8 = int8 weights (both with fp16 activations), WF_FP8 = e4m3 weights and e4m3 activations
-    const int bk = wbits == 16 ? 128 : 256;  // k per sub-block (4 weight loads per lane)
-    if (M < 1 || M > 128 || K % bk || K < 512 || (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) % 16 ||
-        (wbits != 16 && wbits != 8 && wbits != WF_FP8)) {
+int linear_splitk_partial(int wbits, const void *x, const void *W, int M, int K, int N, hipStream_t st, SplitKSlabs *out,
+                          const half_t *gscale) {
+    // wbits: 16 = fp16 weights, 8 = int8 weights, 4 = int4 weights with group-128 scales `gscale` applied in the kernel (all
+    // with fp16 activations), WF_FP8 = e4m3 weights and e4m3 activations
+    const int bk = wbits == 16 ? 128 : (wbits == 4 ? 512 : 256);  // k per sub-block (4 weight loads per lane)
+    if (wbits == 4 && (M > 64 || K % 256 || !gscale || reinterpret_cast<uintptr_t>(gscale) % 4)) {
+        set_error("linear(split-K int4): needs M <= 64 per pass, K %% 256 == 0, group-128 scales");
+        return LLMIE_ERR_UNSUPPORTED;
+    }
+    if (M < 1 || M > 128 || (wbits != 4 && K % bk) || K < 512 || (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) % 16 ||
+        (wbits != 16 && wbits != 8 && wbits != 4 && wbits != WF_FP8)) {
         set_error("linear(split-K): unsupported shape M=%d K=%d (bits=%d)", M, K, wbits);
         return LLMIE_ERR_UNSUPPORTED;
     }
-    const int tiles = (N + 63) / 64, total_blocks = K / bk;
+    const int tiles = (N + 63) / 64, total_blocks = (K + bk - 1) / bk;
     static const int target = env_int("LLMIE_SPLITK_TARGET_WGS", 512);
     // K slices: enough workgroups to fill the chip, but >= 4 sub-blocks per slice (the weight ring depth) and as few
     // slabs as possible (slab traffic = 2 * KS * M * N * 4 bytes)
     int KS = 1;
-    while (KS < 16 && tiles * KS < target && total_blocks / (KS * 2) >= 4) KS *= 2;
+    const int min_blocks = wbits == 4 ? 1 : 4;  // int4 sub-blocks are 512 k wide: K = 4096 has only 8 of them
+    while (KS < 16 && tiles * KS < target && total_blocks / (KS * 2) >= min_blocks) KS *= 2;
     const int spp = (total_blocks + KS - 1) / KS;
     float *slab = splitk_scratch(static_cast<size_t>(KS) * M * N);
     if (!slab) {
@@ -216,9 +223,17 @@ int linear_splitk_partial(int wbits, const void *x, const void *W, int M, int K,
     const int mt = (M + 15) / 16;
     const dim3 grid(tiles * KS);
 #define LLMIE_SK(MT_)                                                                                          \
-    (wbits == 16 ? skinny_splitk_kernel<MT_, 16><<<grid, 256, 0, st>>>(x, W, slab, M, K, N, KS, spp)              \
-     : wbits == 8 ? skinny_splitk_kernel<MT_, 8><<<grid, 256, 0, st>>>(x, W, slab, M, K, N, KS, spp)              \
-                  : skinny_splitk_kernel<MT_, 8, true><<<grid, 256, 0, st>>>(x, W, slab, M, K, N, KS, spp))
+    (wbits == 16 ? skinny_splitk_kernel<MT_, 16><<<grid, 256, 0, st>>>(x, W, slab, M, K, N, KS, spp, nullptr)     \
+     : wbits == 8 ? skinny_splitk_kernel<MT_, 8><<<grid, 256, 0, st>>>(x, W, slab, M, K, N, KS, spp, nullptr)     \
+                  : skinny_splitk_kernel<MT_, 8, true><<<grid, 256, 0, st>>>(x, W, slab, M, K, N, KS, spp, nullptr))
+    if (wbits == 4) {
+        switch (mt) {
+            case 1: skinny_splitk_kernel<1, 4><<<grid, 256, 0, st>>>(x, W, slab, M, K, N, KS, spp, gscale); break;
+            case 2: skinny_splitk_kernel<2, 4><<<grid, 256, 0, st>>>(x, W, slab, M, K, N, KS, spp, gscale); break;
+            case 3: skinny_splitk_kernel<3, 4><<<grid, 256, 0, st>>>(x, W, slab, M, K, N, KS, spp, gscale); break;
+            default: skinny_splitk_kernel<4, 4><<<grid, 256, 0, st>>>(x, W, slab, M, K, N, KS, spp, gscale); break;
+        }
+    } else
     switch (mt) {
         case 1: LLMIE_SK(1); break;
         case 2: LLMIE_SK(2); break;
@@ -240,18 +255,20 @@ int linear_splitk_partial(int wbits, const void *x, const void *W, int M, int K,
 // split-K skinny MFMA path: 8 < M (any M, 128 rows of x per pass); wbits 16 or 8
 int linear_splitk(int wbits, const half_t *x, const void *W, const half_t *scale, half_t *y, int M, int K, int N, int epi,
                   const half_t *bias, const half_t *residual, hipStream_t st) {
-    static const int mpass = env_int("LLMIE_SPLITK_PASS_M", 128);  // activation rows per pass (16 per MFMA tile, <= 128)
+    // wbits 8: `scale` = per-row fp16 scales applied by the finalize; wbits 4: `scale` = group-128 scales applied in the kernel
+    static const int mpass_env = env_int("LLMIE_SPLITK_PASS_M", 128);  // activation rows per pass (16 per MFMA tile, <= 128)
+    const int mpass = wbits == 4 ? 64 : mpass_env;
     const int out_n = epi == EPI_SWIGLU ? N / 2 : N;
     for (int m0 = 0; m0 < M; m0 += mpass) {
         const int mc = M - m0 < mpass ? M - m0 : mpass;
         SplitKSlabs sk;
-        const int rc = linear_splitk_partial(wbits, x + static_cast<size_t>(m0) * K, W, mc, K, N, st, &sk);
+        const int rc = linear_splitk_partial(wbits, x + static_cast<size_t>(m0) * K, W, mc, K, N, st, &sk, wbits == 4 ? scale : nullptr);
         if (rc) return rc;
         const size_t total = static_cast<size_t>(mc) * out_n;
         int fgrid = static_cast<int>((total + 255) / 256);
         if (fgrid > 2048) fgrid = 2048;
         skinny_finalize_kernel<<<fgrid, 256, 0, st>>>(sk.slab, y + static_cast<size_t>(m0) * out_n, mc, N, sk.KS,
-                                                      SlabScale{scale, nullptr, nullptr}, bias,
+                                                      SlabScale{wbits == 4 ? nullptr : scale, nullptr, nullptr}, bias,
                                                       residual ? residual + static_cast<size_t>(m0) * N : nullptr, epi);
     }
     return launch_status("linear(split-K)");

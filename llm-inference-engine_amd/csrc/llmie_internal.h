@@ -23,7 +23,8 @@ struct SplitKSlabs {
     int KS, M, N;
 };
 enum : int { WF_FP8 = 108 };  // wbits code of e4m3 weights + e4m3 activations (16 / 8 = fp16 / int8 weights, fp16 activations)
-int linear_splitk_partial(int wbits, const void *x, const void *W, int M, int K, int N, hipStream_t st, SplitKSlabs *out);
+int linear_splitk_partial(int wbits, const void *x, const void *W, int M, int K, int N, hipStream_t st, SplitKSlabs *out,
+                          const half_t *gscale = nullptr /* wbits 4: group-128 scales [N, K/128], applied in the kernel */);
 int splitk_finalize(const SplitKSlabs &sk, const SlabScale &sc, half_t *y, int epi, const half_t *bias, const half_t *residual,
                     hipStream_t st);
 bool splitk_rownorm_eligible(int N);

@@ -146,8 +146,10 @@ int linear_wq(int wbits, const half_t *x, const void *wq, const half_t *scale, h
         const GemvArgs a{x, wq, y, K, N, bias, residual, gamma, pre_bias, eps, epi, gamma ? 1 : 0, scale, group};
         if (gemv_q_launch(wbits, M, a, st)) return launch_status("linear_wq");
     }
+    if (aligned && wbits == 4 && group == 128 && K % 256 == 0 && K >= 512 && M > 8 && !gamma && !getenv("LLMIE_NO_SPLITK"))
+        return linear_splitk(4, x, wq, scale, y, M, K, N, epi, bias, residual, st);  // MFMA path, group scales in the kernel
     if (aligned && wbits == 4) {
-        // int4 has no MFMA form yet: batches beyond the GEMV's register budget run as row chunks of the largest eligible
+        // other int4 shapes: batches beyond the GEMV's register budget run as row chunks of the largest eligible
         // size (the weights are streamed once per chunk -- correct for any batch, bandwidth-efficient only for small ones)
         int mc = 8;
         while (mc > 0 && !ksplit_eligible(mc, K, 4)) --mc;

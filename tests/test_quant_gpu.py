@@ -69,7 +69,7 @@ def test_linear_w8a16(llmie, M, K, N):
     assert (err <= 2e-3 + 2e-3 * np.abs(exp)).all(), err.max()
 
 
-@pytest.mark.parametrize("M,K,N,group", [(11, 4096, 512, 128), (37, 11008, 256, 128), (1, 4096, 512, 128), (2, 4096, 22016, 128), (4, 4096, 256, 128),
+@pytest.mark.parametrize("M,K,N,group", [(11, 4096, 512, 128), (37, 11008, 256, 128), (64, 4096, 1000, 128), (100, 11008, 4096, 128), (20, 4096, 22016, 128), (1, 4096, 512, 128), (2, 4096, 22016, 128), (4, 4096, 256, 128),
                                          (1, 11008, 4096, 128), (2, 11008, 128, 128), (1, 128, 64, 32)])
 def test_linear_w4a16(llmie, M, K, N, group):
     rng = np.random.default_rng(33)
@@ -96,7 +96,7 @@ def test_linear_w8_fused_bias_residual(llmie):
     assert np.abs(y.float().cpu().numpy() - exp).max() <= 8e-3
 
 
-@pytest.mark.parametrize("fmt,bs", [("int8", 1), ("int8", 4), ("int8", 20), ("int8", 72), ("int4", 1), ("int4", 2), ("int4", 6), ("int4", 19)])
+@pytest.mark.parametrize("fmt,bs", [("int8", 1), ("int8", 4), ("int8", 20), ("int8", 72), ("int4", 1), ("int4", 2), ("int4", 6), ("int4", 19), ("int4", 40), ("int4", 70)])
 def test_quantised_decoder_matches_oracle_on_dequantised_weights(llmie, fmt, bs):
     rng = np.random.default_rng(35)
     nh, hs, I, L, max_seq, step, group = 32, 128, 11008, 1, 96, 40, 128
