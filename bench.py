@@ -401,6 +401,7 @@ def main():
         q8f = quantize_layers(torch, llmie, weights["layers"], "fp8")   # BASELINE configs[4]: fp8 batch sweep at ctx 512
         for b in (1, 32, 128):
             record("decode_fp8_b%d_ctx512" % b, "fp8", q8f, b, 512, 1.0)
+        record("decode_fp8_b128_ctx512_kvfp8", "fp8", q8f, 128, 512, 1.0, True)   # e4m3 weights + e4m3 KV cache
         record_prefill("prefill_fp8_b8_s512", 8, 512, "fp8", q8f)
         record_prefill("prefill_fp8_b1_s2048", 1, 2048, "fp8", q8f)
         del q8f
