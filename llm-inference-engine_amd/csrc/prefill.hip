@@ -208,17 +208,23 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
         // the staging and the barriers above)
         if (t0 > history + q0 + wave * 16 + 15) continue;
         // ---- S^T = K . Q^T : 4 key tiles of 16, 4 k-steps over the head dim ----
-        floatx4 sacc[4];
+        // all 16 K fragments of the tile are read before the first MFMA (the compiler's own order was read -> wait -> MFMA,
+        // one LDS round trip per MFMA)
+        half8_t kfr[4][4];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
-            sacc[tt] = floatx4{0.f, 0.f, 0.f, 0.f};
             const int row = tt * 16 + r;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const half8_t kf = *reinterpret_cast<const half8_t *>(Ks + row * HS + (((s * 4 + q) ^ (row & 15)) << 3));
-                sacc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[s], sacc[tt], 0, 0, 0);
-            }
+            for (int s = 0; s < 4; ++s) kfr[tt][s] = *reinterpret_cast<const half8_t *>(Ks + row * HS + (((s * 4 + q) ^ (row & 15)) << 3));
         }
+        __builtin_amdgcn_sched_barrier(0);
+        floatx4 sacc[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) sacc[tt] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)  // 4 independent accumulators per k-step: no back-to-back dependent MFMAs
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) sacc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[tt][s], qf[s], sacc[tt], 0, 0, 0);
         // lane holds S[qrow][t = t0 + 16 tt + 4 q + e]; mask + scale
         float mloc = -INFINITY;
 #pragma unroll
