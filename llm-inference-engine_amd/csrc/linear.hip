@@ -190,6 +190,33 @@ static float *splitk_scratch(size_t floats) {
     return buf;
 }
 
+// y = sum over the KS slabs (* scales of the weight format) (+bias)(+residual) | SwiGLU over (n, N/2+n)
+static __global__ __launch_bounds__(256) void skinny_finalize_kernel(const float *__restrict__ slab, half_t *y, int M, int N, int KS,
+                                                              const SlabScale scale, const half_t *__restrict__ bias,
+                                                              const half_t *residual, int epi) {
+    const int out_n = epi == EPI_SWIGLU ? N / 2 : N;
+    const size_t total = static_cast<size_t>(M) * out_n;
+    const size_t slab_sz = static_cast<size_t>(M) * N;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * 256) {
+        const int m = static_cast<int>(i / out_n), n = static_cast<int>(i - static_cast<size_t>(m) * out_n);
+        auto gather = [&](int col) {
+            float v = 0.f;
+            for (int k = 0; k < KS; ++k) v += slab[k * slab_sz + static_cast<size_t>(m) * N + col];
+            return scale.apply(v, m, col);
+        };
+        float v;
+        if (epi == EPI_SWIGLU) {
+            const float gt = gather(n), up = gather(n + out_n);
+            v = (gt / (1.0f + expf(-gt))) * up;
+        } else {
+            v = gather(n);
+            if (bias) v += to_f32(bias[n]);
+            if (residual) v += to_f32(residual[static_cast<size_t>(m) * N + n]);
+        }
+        y[static_cast<size_t>(m) * out_n + n] = from_f32<half_t>(v);
+    }
+}
+
 // split-K skinny MFMA path, first half: partial products of one pass (8 < M <= 128) into the library's fp32 slabs
 // [KS][M][N].  The slabs stay valid until the next split-K launch on the stream; the consumer (finalize kernel,
 // splitk_rownorm, or the decode attention reading q/k/v straight from the slabs) must be enqueued before it.
