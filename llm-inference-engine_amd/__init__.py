@@ -78,6 +78,8 @@ _SIGS = {
     "llmie_lm_head_sample": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp,
                              _i, _vp],
     "llmie_advance_step": [_vp, _vp],
+    "llmie_decoder_forward_paged": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "llmie_kv_pages_copy": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "llmie_decoder_profile_begin": [_vp, _i],
     "llmie_decoder_profile_end": [_vp, _vp, _vp, _vp],
     "llmie_abi_version": [],
@@ -340,6 +342,13 @@ class Decoder:
                                            hidden_in.shape[0], step, _p(step_dev), _st()), "decoder_forward")
         return hidden_out
 
+    def forward_paged(self, hidden_in, hidden_out, k_pool, v_pool, block_table, step, step_dev=None):
+        """pools [L, num_pages, kvh, 128, hs]; block_table int32 [batch, max_pages] (device)"""
+        _check(lib().llmie_decoder_forward_paged(self.handle, _p(hidden_in), _p(hidden_out), _p(k_pool), _p(v_pool),
+                                                 _p(block_table), block_table.shape[1], k_pool.shape[1], hidden_in.shape[0],
+                                                 step, _p(step_dev), _st()), "decoder_forward_paged")
+        return hidden_out
+
     def prefill(self, hidden_in, hidden_out, k_cache, v_cache, input_lengths, history_lengths, max_q_len):
         import torch
         T, bs = hidden_in.shape[0], input_lengths.numel()
@@ -407,6 +416,17 @@ def linear_w4a16(x, wq, scale, y, group, bias=None, residual=None):
 
 def quantize_fp8(w, wq, scale):
     _check(lib().llmie_quantize_fp8(_p(w), _p(wq), _p(scale), w.shape[0], w.shape[1], _st()), "quantize_fp8")
+
+
+KV_PAGE_TOKENS = 128
+
+
+def kv_pages_copy(dense, pool, block_table, ctx_len, to_pages):
+    """dense [L, batch, kvh, max_seq, hs] <-> pool [L, num_pages, kvh, 128, hs] for the first ctx_len[b] tokens of each sequence"""
+    L, batch, kvh, max_seq, hs = dense.shape
+    _check(lib().llmie_kv_pages_copy(_p(dense), _p(pool), _p(block_table), _p(ctx_len), 1 if to_pages else 0, L, batch, kvh,
+                                     max_seq, hs, block_table.shape[1], pool.shape[1], dense.element_size(), _st()),
+           "kv_pages_copy")
 
 
 def linear_fp8_workspace_bytes(M, K):

@@ -93,6 +93,14 @@ struct QkvSlabs {
     SlabScale sc;           // scales of the projection's weight format (int8: per channel; fp8: channel x token)
 };
 
+// Paged KV cache: pool [L][num_pages][kvh][KV_PAGE tokens][hs]; block_table[b * max_pages + p] = pool page of
+// the p-th page of sequence b.  table == null: the reference's dense [L][batch][kvh][max_seq][hs] slab.
+constexpr int KV_PAGE = 128;
+struct PagedKv {
+    const int32_t *table;
+    int max_pages;
+};
+
 // Merge of the per-split (m, l, o[d]) partials of one (batch, head) for output dim d: 16 splits per round,
 // every load of a round issued before the first use.  Shared by the stand-alone merge kernel and by the
 // in-kernel merge of the last-arriving workgroup, so both give bit-identical results.
@@ -134,7 +142,8 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
     const float2 *__restrict__ rope /* [max_pos][HS/2] (cos,sin) or null */, int rotary_dim,
     int32_t *tickets /* [batch, kv_head_num] zero-initialised arrival counters, or null = separate merge kernel */,
     const QkvSlabs qs /* qs.slab != null: q/k/v come from the split-K partial slabs of the QKV projection (qkv unused) */,
-    const float k_scale, const float v_scale /* fp8 cache: stored = e4m3(x / scale); 1 otherwise */) {
+    const float k_scale, const float v_scale /* fp8 cache: stored = e4m3(x / scale); 1 otherwise */,
+    const PagedKv pg /* pg.table != null: k_cache / v_cache are this layer's page pools */) {
     using G = AttnGeom<KT, HS, kAttnWaves, kAttnG>;
     using V = typename CacheVec<KT>::type;  // one 16-byte vector of cache elements
     constexpr int N = G::N, LPT = G::LPT, TPW = G::TPW, CHUNK = G::CHUNK;
@@ -156,9 +165,28 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
 
     const T *row = qkv + static_cast<size_t>(b) * qkv_heads * HS;
     // q for the REP heads of this kv head, pre-scaled, fp32
-    const size_t head_off = (static_cast<size_t>(b) * kv_head_num + g) * max_seq_len * HS;
-    KT *kc = k_cache + head_off;
-    KT *vc = v_cache + head_off;
+    // Cache rows of this workgroup's chunk: one base pointer per 128-token page the chunk touches (1 or 2).  Dense layout: the
+    // page-aligned pieces of the head's contiguous [max_seq][HS] slab; paged: looked up ONCE here in the block table (uniform
+    // scalar loads), so the K/V loads below never depend on a table load.
+    constexpr int NPG = CHUNK > KV_PAGE ? CHUNK / KV_PAGE : 1;
+    static_assert(CHUNK % KV_PAGE == 0 || KV_PAGE % CHUNK == 0, "chunk vs page size");
+    const int pg0 = t0 / KV_PAGE;
+    KT *kbase[NPG], *vbase[NPG];
+#pragma unroll
+    for (int j = 0; j < NPG; ++j) {
+        size_t off;
+        if (pg.table) {
+            const int page = pg.table[static_cast<size_t>(b) * pg.max_pages + min(pg0 + j, pg.max_pages - 1)];
+            off = (static_cast<size_t>(page) * kv_head_num + g) * KV_PAGE * HS;
+        } else {
+            off = (static_cast<size_t>(b) * kv_head_num + g) * max_seq_len * HS + static_cast<size_t>(pg0 + j) * KV_PAGE * HS;
+        }
+        kbase[j] = k_cache + off;
+        vbase[j] = v_cache + off;
+    }
+    auto krow = [&](int t) { return kbase[NPG == 1 ? 0 : (t / KV_PAGE - pg0)] + static_cast<size_t>(t % KV_PAGE) * HS; };
+    auto vrow = [&](int t) { return vbase[NPG == 1 ? 0 : (t / KV_PAGE - pg0)] + static_cast<size_t>(t % KV_PAGE) * HS; };
+    KT *kc = kbase[0];  // a readable address of this head (dummy source of the unconditional loads below)
     const int t_new = step - 1;
     // small L2-resident operands first (q rows, RoPE row), then the K/V stream; q is processed after the K/V
     // loads have been issued, so its latency hides under theirs (vmcnt retires in order: q is older)
@@ -227,11 +255,11 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
         tok[i] = t;
         // rows past the chunk end re-read its last row (masked below); the slot of this step's token is read as it is
         // (stale, replaced below): every load is unconditional so all 2*G of them are in flight together
-        kv[i] = load_nt(reinterpret_cast<const V *>(kc + static_cast<size_t>(min(t, t_end - 1)) * HS) + dl);
+        kv[i] = load_nt(reinterpret_cast<const V *>(krow(min(t, t_end - 1))) + dl);
     }
 #pragma unroll
     for (int i = 0; i < kAttnG; ++i)
-        vv[i] = load_nt(reinterpret_cast<const V *>(vc + static_cast<size_t>(min(tok[i], t_end - 1)) * HS) + dl);
+        vv[i] = load_nt(reinterpret_cast<const V *>(vrow(min(tok[i], t_end - 1))) + dl);
     if (qs.slab) {
 #pragma unroll
         for (int lr = 0; lr < LROUNDS; ++lr) {
@@ -337,8 +365,8 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
             vv[i] = __builtin_bit_cast(V, vw);
         }
         if (mine) {
-            reinterpret_cast<V *>(kc + static_cast<size_t>(t_new) * HS)[dl] = knv;
-            reinterpret_cast<V *>(vc + static_cast<size_t>(t_new) * HS)[dl] = vnv;
+            reinterpret_cast<V *>(krow(t_new))[dl] = knv;
+            reinterpret_cast<V *>(vrow(t_new))[dl] = vnv;
         }
     }
 
@@ -560,7 +588,7 @@ template <typename T, int HS, int REP, typename KT = T>
 static void launch_split(const T *qkv, const T *bias, KT *kc, KT *vc, float *part, T *out, int batch,
                          int head_num, int kv_head_num, int max_seq_len, int step, const int32_t *step_dev,
                          int max_splits_ws, const float2 *rope, int rot_dim, int32_t *tickets, const QkvSlabs &qs,
-                         KvScale ks, hipStream_t st) {
+                         KvScale ks, PagedKv pg, hipStream_t st) {
     static const int cfg = getenv("LLMIE_ATTN_CFG") ? atoi(getenv("LLMIE_ATTN_CFG")) : 0;
     const int bound = step_dev ? max_seq_len : step;
     int CHUNK, splits;
@@ -571,7 +599,7 @@ static void launch_split(const T *qkv, const T *bias, KT *kc, KT *vc, float *par
         dim3 grid(splits, kv_head_num, batch);                                                                          \
         decode_attn_split_kernel<T, HS, REP, NWV_, GL_, KT><<<grid, NWV_ * 64, 0, st>>>(                                \
             qkv, bias, kc, vc, part, out, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, \
-            tickets, qs, ks.k, ks.v);                                                                                   \
+            tickets, qs, ks.k, ks.v, pg);                                                                               \
     } while (0)
     if (cfg == 1) LLMIE_ATTN_LAUNCH(8, 8);
     else if (cfg == 2) LLMIE_ATTN_LAUNCH(4, 4);
@@ -588,14 +616,14 @@ template <typename T, int HS, typename KT = T>
 static bool dispatch_rep(int rep, const T *qkv, const T *bias, KT *kc, KT *vc, float *part, T *out, int batch,
                          int head_num, int kv_head_num, int max_seq_len, int step, const int32_t *step_dev,
                          int max_splits_ws, const float2 *rope, int rot_dim, int32_t *tickets, const QkvSlabs &qs,
-                         KvScale ks, hipStream_t st) {
+                         KvScale ks, PagedKv pg, hipStream_t st) {
     switch (rep) {
-        case 1: launch_split<T, HS, 1, KT>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, ks, st); return true;
-        case 2: launch_split<T, HS, 2, KT>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, ks, st); return true;
-        case 4: launch_split<T, HS, 4, KT>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, ks, st); return true;
+        case 1: launch_split<T, HS, 1, KT>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, ks, pg, st); return true;
+        case 2: launch_split<T, HS, 2, KT>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, ks, pg, st); return true;
+        case 4: launch_split<T, HS, 4, KT>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, ks, pg, st); return true;
         case 8:
             if constexpr (!std::is_same<KT, T>::value) return false;  // fp8 cache: 16 dims per lane x 8 heads does not fit registers
-            else launch_split<T, HS, 8, KT>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, ks, st); return true;
+            else launch_split<T, HS, 8, KT>(qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, ks, pg, st); return true;
         default: return false;
     }
 }
@@ -604,8 +632,10 @@ template <typename T>
 static int decoder_mha_impl(const T *qkv, const T *bias, T *k_cache, T *v_cache, T *out, int layer, int batch,
                             int head_num, int kv_head_num, int head_size, int max_seq_len, int step,
                             const int32_t *step_dev, void *workspace, size_t workspace_bytes, const float2 *rope,
-                            int rot_dim, int32_t *tickets, const QkvSlabs &qs, hipStream_t st) {
-    const size_t layer_off = static_cast<size_t>(layer) * batch * kv_head_num * max_seq_len * head_size;
+                            int rot_dim, int32_t *tickets, const QkvSlabs &qs, hipStream_t st, PagedKv pg = PagedKv{nullptr, 0},
+                            int num_pages = 0) {
+    const size_t layer_off = pg.table ? static_cast<size_t>(layer) * num_pages * kv_head_num * KV_PAGE * head_size
+                                      : static_cast<size_t>(layer) * batch * kv_head_num * max_seq_len * head_size;
     T *kc = k_cache + layer_off, *vc = v_cache + layer_off;
     const int rep = head_num / kv_head_num;
     const int max_splits_ws = (max_seq_len + attn_min_chunk() - 1) / attn_min_chunk();
@@ -617,18 +647,22 @@ static int decoder_mha_impl(const T *qkv, const T *bias, T *k_cache, T *v_cache,
         float *part = static_cast<float *>(workspace);
         auto ws_ok = [&]() { return workspace && workspace_bytes >= need; };
         if (head_size == 128 && ws_ok())
-            done = dispatch_rep<T, 128>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, KvScale{1.f, 1.f}, st);
+            done = dispatch_rep<T, 128>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, KvScale{1.f, 1.f}, pg, st);
         else if (head_size == 64 && ws_ok())
-            done = dispatch_rep<T, 64>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, KvScale{1.f, 1.f}, st);
+            done = dispatch_rep<T, 64>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, KvScale{1.f, 1.f}, pg, st);
         else if (head_size == 32 && ws_ok())
-            done = dispatch_rep<T, 32>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, KvScale{1.f, 1.f}, st);
+            done = dispatch_rep<T, 32>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, KvScale{1.f, 1.f}, pg, st);
         else if (head_size == 256 && ws_ok())
-            done = dispatch_rep<T, 256>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, KvScale{1.f, 1.f}, st);
+            done = dispatch_rep<T, 256>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, tickets, qs, KvScale{1.f, 1.f}, pg, st);
         if (!done && (head_size == 128 || head_size == 64 || head_size == 32 || head_size == 256) && !ws_ok() &&
             (rep == 1 || rep == 2 || rep == 4 || rep == 8)) {
             set_error("decoder_mha: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
             return LLMIE_ERR_WORKSPACE;
         }
+    }
+    if (!done && pg.table) {
+        set_error("decoder_mha: the paged KV cache needs head_size in {32,64,128,256} and head_num/kv_head_num in {1,2,4,8}");
+        return LLMIE_ERR_UNSUPPORTED;
     }
     if (!done && qs.slab) {
         set_error("decoder_mha: q/k/v from split-K slabs needs head_size in {32,64,128,256} and head_num/kv_head_num in {1,2,4,8}");
@@ -657,8 +691,9 @@ static int decoder_mha_impl(const T *qkv, const T *bias, T *k_cache, T *v_cache,
 static int decoder_mha_fp8kv(const half_t *qkv, const half_t *bias, uint8_t *k_cache, uint8_t *v_cache, half_t *out, int layer, int batch,
                              int head_num, int kv_head_num, int head_size, int max_seq_len, int step, const int32_t *step_dev,
                              void *workspace, size_t workspace_bytes, const float2 *rope, int rot_dim, const QkvSlabs &qs,
-                             KvScale ks, hipStream_t st) {
-    const size_t layer_off = static_cast<size_t>(layer) * batch * kv_head_num * max_seq_len * head_size;
+                             KvScale ks, hipStream_t st, PagedKv pg, int num_pages) {
+    const size_t layer_off = pg.table ? static_cast<size_t>(layer) * num_pages * kv_head_num * KV_PAGE * head_size
+                                      : static_cast<size_t>(layer) * batch * kv_head_num * max_seq_len * head_size;
     fp8kv_t *kc = reinterpret_cast<fp8kv_t *>(k_cache) + layer_off, *vc = reinterpret_cast<fp8kv_t *>(v_cache) + layer_off;
     const int rep = head_num / kv_head_num;
     const int max_splits_ws = (max_seq_len + attn_min_chunk() - 1) / attn_min_chunk();
@@ -674,10 +709,10 @@ static int decoder_mha_fp8kv(const half_t *qkv, const half_t *bias, uint8_t *k_c
     bool done;
     if (head_size == 128)
         done = dispatch_rep<half_t, 128, fp8kv_t>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step,
-                                                  step_dev, max_splits_ws, rope, rot_dim, nullptr, qs, ks, st);
+                                                  step_dev, max_splits_ws, rope, rot_dim, nullptr, qs, ks, pg, st);
     else
         done = dispatch_rep<half_t, 64, fp8kv_t>(rep, qkv, bias, kc, vc, part, out, batch, head_num, kv_head_num, max_seq_len, step,
-                                                 step_dev, max_splits_ws, rope, rot_dim, nullptr, qs, ks, st);
+                                                 step_dev, max_splits_ws, rope, rot_dim, nullptr, qs, ks, pg, st);
     (void)done;
     return launch_status("decoder_mha(fp8 KV)");
 }
@@ -687,7 +722,12 @@ int decoder_mha_rope(const void *qkv, const void *qkv_bias, void *k_cache, void 
                      int head_num, int kv_head_num, int head_size, int max_seq_len, int step, const int32_t *step_dev,
                      void *workspace, size_t workspace_bytes, const float2 *rope, int rot_dim, int32_t *tickets,
                      llmie_dtype dtype, hipStream_t st, const SplitKSlabs *qkv_slabs, const SlabScale *qkv_scale, int kv_fp8,
-                     float k_scale, float v_scale) {
+                     float k_scale, float v_scale, const int32_t *block_table, int max_pages, int num_pages) {
+    const PagedKv pg{block_table, max_pages};
+    if (block_table && (max_pages <= 0 || num_pages <= 0 || static_cast<long long>(max_pages) * KV_PAGE < max_seq_len)) {
+        set_error("decoder_mha: paged KV cache needs max_pages * %d >= max_seq_len and num_pages > 0", KV_PAGE);
+        return LLMIE_ERR_UNSUPPORTED;
+    }
     QkvSlabs qs{nullptr, 0, 0, SlabScale{nullptr, nullptr, nullptr}};
     const SlabScale no_scale{nullptr, nullptr, nullptr};
     const SlabScale &qsc = qkv_scale ? *qkv_scale : no_scale;
@@ -705,15 +745,15 @@ int decoder_mha_rope(const void *qkv, const void *qkv_bias, void *k_cache, void 
         }
         return decoder_mha_fp8kv((const half_t *)qkv, (const half_t *)qkv_bias, (uint8_t *)k_cache, (uint8_t *)v_cache, (half_t *)out,
                                  layer, batch, head_num, kv_head_num, head_size, max_seq_len, step, step_dev, workspace,
-                                 workspace_bytes, rope, rot_dim, qs, KvScale{k_scale, v_scale}, st);
+                                 workspace_bytes, rope, rot_dim, qs, KvScale{k_scale, v_scale}, st, pg, num_pages);
     }
     if (dtype == LLMIE_F32)
         return decoder_mha_impl<float>((const float *)qkv, (const float *)qkv_bias, (float *)k_cache, (float *)v_cache,
                                        (float *)out, layer, batch, head_num, kv_head_num, head_size, max_seq_len, step,
-                                       step_dev, workspace, workspace_bytes, rope, rot_dim, tickets, qs, st);
+                                       step_dev, workspace, workspace_bytes, rope, rot_dim, tickets, qs, st, pg, num_pages);
     return decoder_mha_impl<half_t>((const half_t *)qkv, (const half_t *)qkv_bias, (half_t *)k_cache, (half_t *)v_cache,
                                     (half_t *)out, layer, batch, head_num, kv_head_num, head_size, max_seq_len, step,
-                                    step_dev, workspace, workspace_bytes, rope, rot_dim, tickets, qs, st);
+                                    step_dev, workspace, workspace_bytes, rope, rot_dim, tickets, qs, st, pg, num_pages);
 }
 
 }  // namespace llmie

@@ -32,6 +32,9 @@ struct llmie_decoder {
     void *fp8_ws;        // LLMIE_W_FP8 engines: activation quantisation + split-K scratch of llmie_linear_fp8
     size_t fp8_ws_bytes;
     int32_t *tickets;    // [max_batch, kv_head_num] arrival counters of the in-launch attention merge (zero between launches)
+    // paged KV cache of the current llmie_decoder_forward_paged call (null: dense caches)
+    const int32_t *page_table = nullptr;
+    int max_pages = 0, num_pages = 0;
     // profiling (eager only)
     bool profiling = false;
     std::vector<hipEvent_t> ev;      // pairs: start, stop
@@ -368,8 +371,8 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
             TIMED(LLMIE_OP_MHA, decoder_mha_rope(dec->qkv, w.qkv.bias, k_cache, v_cache, dec->mha, l, batch, c.head_num,
                                                  c.kv_head_num, c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws,
                                                  dec->attn_ws_bytes, dec->rope_table, c.rotary_dim,
-                                                 (merge_in_kernel && !kv8) ? dec->tickets : nullptr, dt, st, nullptr, nullptr, kv8,
-                                                 k_scale, v_scale));
+                                                 (merge_in_kernel && !kv8 && !dec->page_table) ? dec->tickets : nullptr, dt, st, nullptr,
+                                                 nullptr, kv8, k_scale, v_scale, dec->page_table, dec->max_pages, dec->num_pages));
             TIMED(LLMIE_OP_O_GEMM, lin(dec->mha, w.o, h, H, H, EPI_NONE_, h, nullptr, nullptr));
             TIMED(LLMIE_OP_GATE_UP_SWIGLU, lin(h, w.gate_up, dec->act, H, 2 * I, EPI_SWIGLU_, nullptr, w.ffn_norm_gamma, w.o.bias));
             TIMED(LLMIE_OP_DOWN_GEMM, lin(dec->act, w.down, h, I, H, EPI_NONE_, h, nullptr, nullptr));
@@ -420,7 +423,7 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
             TIMED(LLMIE_OP_MHA, decoder_mha_rope(nullptr, w.qkv.bias, k_cache, v_cache, dec->mha, l, batch, c.head_num,
                                                  c.kv_head_num, c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws,
                                                  dec->attn_ws_bytes, dec->rope_table, c.rotary_dim, nullptr, dt, st, &sk, &qsc, kv8,
-                                                 k_scale, v_scale));
+                                                 k_scale, v_scale, dec->page_table, dec->max_pages, dec->num_pages));
             if (fp8) TIMED(LLMIE_OP_O_GEMM, quantize_rows_fp8(mha, xqB, xsB, batch, H, st));
             TIMED(LLMIE_OP_O_GEMM, linear_splitk_partial(fmt, fp8 ? static_cast<const void *>(xqB) : mha, w.o.data, batch, H, H, st, &sk, gs_of(w.o)));
             // self_decoder.cpp:92  h += resid; resid = h; h += o.bias; h = rmsnorm(h, ffn_gamma)
@@ -440,6 +443,10 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
         return LLMIE_OK;
     }
 
+    if (dec->page_table) {
+        set_error("decoder_forward_paged: the paged KV cache needs the fused decode paths (fp16 engines, batch <= 128)");
+        return LLMIE_ERR_UNSUPPORTED;
+    }
     if (kv8) {
         set_error("decoder_forward: the fp8 KV cache needs the fused decode paths (batch <= 128, fp16/int8/int4/fp8 weights with "
                   "H and I multiples of 256 at batch > 8)");
@@ -477,6 +484,22 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
         TIMED(LLMIE_OP_DOWN_GEMM, engine_linear(dec, c.wfmt, dec->act, w.down, h, batch, I, H, false, dec->resid, false, stream));
     }
     return LLMIE_OK;
+}
+
+extern "C" int llmie_decoder_forward_paged(llmie_decoder *dec, const void *hidden_in, void *hidden_out, void *k_pool, void *v_pool,
+                                           const int32_t *block_table, int max_pages, int num_pages, int batch, int step,
+                                           const int32_t *step_dev, llmie_stream stream) {
+    LLMIE_REQUIRE(dec && block_table, "decoder_forward_paged: NULL pointer");
+    LLMIE_REQUIRE(max_pages > 0 && num_pages > 0 &&
+                      static_cast<long long>(max_pages) * LLMIE_KV_PAGE_TOKENS >= dec->cfg.max_seq_len,
+                  "decoder_forward_paged: max_pages * %d must cover max_seq_len %d", LLMIE_KV_PAGE_TOKENS, dec->cfg.max_seq_len);
+    dec->page_table = block_table;
+    dec->max_pages = max_pages;
+    dec->num_pages = num_pages;
+    const int rc = llmie_decoder_forward(dec, hidden_in, hidden_out, k_pool, v_pool, batch, step, step_dev, stream);
+    dec->page_table = nullptr;
+    dec->max_pages = dec->num_pages = 0;
+    return rc;
 }
 
 static size_t prefill_carve(const llmie_decoder_config *c, int T, int B, size_t *o /*[8]*/) {

@@ -261,3 +261,41 @@ extern "C" int llmie_repeat_kv(const void *cache, void *dst, const int32_t *ctx_
                                             max_k_len, max_seq_len, head_size, as_stream(stream));
     LLMIE_UNSUPPORTED("repeat_kv: dtype %d", (int)dtype);
 }
+
+// dense [L, batch, kvh, max_seq, hs] <-> page pools [L, num_pages, kvh, 128, hs] through the block table; one workgroup per
+// (token, kv head, batch), 16-byte accesses when the row allows, plain bytes otherwise; bit-exact copy
+namespace llmie {
+__global__ __launch_bounds__(64) void kv_pages_copy_kernel(unsigned char *dense, unsigned char *pool, const int32_t *__restrict__ table,
+                                                           const int32_t *__restrict__ ctx_len, int to_pages, int batch, int kvh,
+                                                           int max_seq, int row_bytes, int max_pages, int num_pages) {
+    const int t = blockIdx.x, g = blockIdx.y, lb = blockIdx.z;  // lb = layer * batch + b
+    const int b = lb % batch, layer = lb / batch;
+    if (t >= ctx_len[b]) return;
+    const int page = table[static_cast<size_t>(b) * max_pages + t / 128];
+    unsigned char *d = dense + ((static_cast<size_t>(lb) * kvh + g) * max_seq + t) * row_bytes;
+    unsigned char *p = pool + (((static_cast<size_t>(layer) * num_pages + page) * kvh + g) * 128 + t % 128) * row_bytes;
+    unsigned char *dst = to_pages ? p : d;
+    const unsigned char *src = to_pages ? d : p;
+    if (row_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 16 == 0) {
+        for (int i = threadIdx.x; i < row_bytes / 16; i += 64) reinterpret_cast<uint4_t *>(dst)[i] = reinterpret_cast<const uint4_t *>(src)[i];
+    } else {
+        for (int i = threadIdx.x; i < row_bytes; i += 64) dst[i] = src[i];
+    }
+}
+}  // namespace llmie
+
+extern "C" int llmie_kv_pages_copy(void *dense, void *pool, const int32_t *block_table, const int32_t *ctx_len, int to_pages,
+                                   int layers, int batch, int kv_head_num, int max_seq_len, int head_size, int max_pages,
+                                   int num_pages, int elem_bytes, llmie_stream stream) {
+    LLMIE_REQUIRE(dense && pool && block_table && ctx_len, "kv_pages_copy: NULL pointer");
+    LLMIE_REQUIRE(layers > 0 && batch > 0 && kv_head_num > 0 && max_seq_len > 0 && head_size > 0 && max_pages > 0 && num_pages > 0 &&
+                      elem_bytes > 0, "kv_pages_copy: bad shape");
+    LLMIE_REQUIRE(static_cast<long long>(max_pages) * 128 >= max_seq_len, "kv_pages_copy: max_pages * 128 < max_seq_len");
+    LLMIE_REQUIRE(kv_head_num <= 65535 && static_cast<long long>(layers) * batch <= 65535, "kv_pages_copy: grid too large");
+    dim3 grid(max_seq_len, kv_head_num, layers * batch);
+    llmie::kv_pages_copy_kernel<<<grid, 64, 0, llmie::as_stream(stream)>>>(static_cast<unsigned char *>(dense), static_cast<unsigned char *>(pool),
+                                                                        block_table, ctx_len, to_pages, batch, kv_head_num, max_seq_len,
+                                                                        head_size * elem_bytes, max_pages, num_pages);
+    return llmie::launch_status("kv_pages_copy");
+}
+

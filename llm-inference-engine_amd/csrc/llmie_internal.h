@@ -64,7 +64,10 @@ int decoder_mha_rope(const void *qkv, const void *qkv_bias, void *k_cache, void 
                      llmie_dtype dtype, hipStream_t st,
                      const SplitKSlabs *qkv_slabs = nullptr /* q/k/v read from the QKV projection's split-K slabs (qkv unused) */,
                      const SlabScale *qkv_scale = nullptr,
-                     int kv_fp8 = 0 /* caches are e4m3 bytes, stored = e4m3(x / scale) */, float k_scale = 1.f, float v_scale = 1.f);
+                     int kv_fp8 = 0 /* caches are e4m3 bytes, stored = e4m3(x / scale) */, float k_scale = 1.f, float v_scale = 1.f,
+                     const int32_t *block_table = nullptr /* paged cache: [batch, max_pages] pool pages of 128 tokens; the cache
+                                                             pointers are then pools [L, num_pages, kvh, 128, hs] */,
+                     int max_pages = 0, int num_pages = 0);
 
 // prefill attention (RoPE + KV append + flash attention) on the packed QKV buffer; prefill.hip
 int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, void *k_cache, void *v_cache, half_t *out,
