@@ -295,12 +295,17 @@ int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, void *hidde
  * [L, num_pages, kvh, LLMIE_KV_PAGE_TOKENS, hs] (element type = the engine's kv_fmt) and block_table[b * max_pages + p]
  * (device int32) names the pool page holding tokens [128 p, 128 p + 128) of sequence b.  Same arithmetic as
  * llmie_decoder_forward (bit-identical outputs for the same cache contents); fused decode paths only.
+ * llmie_decoder_prefill_paged is llmie_decoder_prefill writing / reading the pages directly.
  * llmie_kv_pages_copy moves the first ctx_len[b] tokens of every sequence between a dense cache
  * [L, batch, kvh, max_seq, hs] and the pools (to_pages != 0: dense -> pages, e.g. after llmie_decoder_prefill). */
 #define LLMIE_KV_PAGE_TOKENS 128
 int llmie_decoder_forward_paged(llmie_decoder *dec, const void *hidden_in, void *hidden_out, void *k_pool, void *v_pool,
                                 const int32_t *block_table, int max_pages, int num_pages, int batch, int step,
                                 const int32_t *step_dev, llmie_stream stream);
+int llmie_decoder_prefill_paged(llmie_decoder *dec, const void *hidden_in, void *hidden_out, void *k_pool, void *v_pool,
+                                const int32_t *block_table, int max_pages, int num_pages, const int32_t *input_lengths,
+                                const int32_t *history_lengths, int batch, int num_tokens, int max_q_len, void *workspace,
+                                size_t workspace_bytes, llmie_stream stream);
 int llmie_kv_pages_copy(void *dense, void *pool, const int32_t *block_table, const int32_t *ctx_len, int to_pages,
                         int layers, int batch, int kv_head_num, int max_seq_len, int head_size, int max_pages,
                         int num_pages, int elem_bytes, llmie_stream stream);

@@ -79,6 +79,7 @@ _SIGS = {
                              _i, _vp],
     "llmie_advance_step": [_vp, _vp],
     "llmie_decoder_forward_paged": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "llmie_decoder_prefill_paged": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _sz, _vp],
     "llmie_kv_pages_copy": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "llmie_decoder_profile_begin": [_vp, _i],
     "llmie_decoder_profile_end": [_vp, _vp, _vp, _vp],
@@ -358,6 +359,19 @@ class Decoder:
         _check(lib().llmie_decoder_prefill(self.handle, _p(hidden_in), _p(hidden_out), _p(k_cache), _p(v_cache),
                                            _p(input_lengths), _p(history_lengths), bs, T, max_q_len,
                                            self._pf_ws.data_ptr(), self._pf_ws.numel(), _st()), "decoder_prefill")
+        return hidden_out
+
+    def prefill_paged(self, hidden_in, hidden_out, k_pool, v_pool, block_table, input_lengths, history_lengths, max_q_len):
+        """prefill on the paged cache of forward_paged (pools [L, num_pages, kvh, 128, hs])"""
+        import torch
+        T, bs = hidden_in.shape[0], input_lengths.numel()
+        need = lib().llmie_decoder_prefill_workspace_bytes(C.byref(self.cfg), T, bs)
+        if getattr(self, "_pf_ws", None) is None or self._pf_ws.numel() < need:
+            self._pf_ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+        _check(lib().llmie_decoder_prefill_paged(self.handle, _p(hidden_in), _p(hidden_out), _p(k_pool), _p(v_pool),
+                                                 _p(block_table), block_table.shape[1], k_pool.shape[1], _p(input_lengths),
+                                                 _p(history_lengths), bs, T, max_q_len, self._pf_ws.data_ptr(),
+                                                 self._pf_ws.numel(), _st()), "decoder_prefill_paged")
         return hidden_out
 
     def lm_head_sample(self, hidden, final_gamma, lm_head, lm_fmt, logits, tmp_ids, tmp_vals, topk_ids, topk_vals,

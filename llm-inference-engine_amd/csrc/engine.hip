@@ -577,7 +577,7 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
                                                   history_lengths, dec->rope_table, l, batch, T, max_q_len, c.head_num,
                                                   c.kv_head_num, c.head_size, c.max_seq_len, c.rotary_dim, st,
                                                   c.kv_fmt == LLMIE_KV_FP8, c.k_scale > 0.f ? c.k_scale : 1.f,
-                                                  c.v_scale > 0.f ? c.v_scale : 1.f));
+                                                  c.v_scale > 0.f ? c.v_scale : 1.f, dec->page_table, dec->max_pages, dec->num_pages));
         TIMED(LLMIE_OP_O_GEMM, proj(attn, w.o, h, H, H, nullptr));
         TIMED(LLMIE_OP_FFN_NORM, llmie_fused_add_bias_residual_rmsnorm(resid, h, w.o.bias, w.ffn_norm_gamma, c.rms_eps, T, H,
                                                                        LLMIE_F16, stream));
@@ -594,6 +594,24 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
         TIMED(LLMIE_OP_DOWN_GEMM, proj(act, w.down, h, I, H, resid));
     }
     return LLMIE_OK;
+}
+
+extern "C" int llmie_decoder_prefill_paged(llmie_decoder *dec, const void *hidden_in, void *hidden_out, void *k_pool, void *v_pool,
+                                           const int32_t *block_table, int max_pages, int num_pages, const int32_t *input_lengths,
+                                           const int32_t *history_lengths, int batch, int num_tokens, int max_q_len,
+                                           void *workspace, size_t workspace_bytes, llmie_stream stream) {
+    LLMIE_REQUIRE(dec && block_table, "decoder_prefill_paged: NULL pointer");
+    LLMIE_REQUIRE(max_pages > 0 && num_pages > 0 &&
+                      static_cast<long long>(max_pages) * LLMIE_KV_PAGE_TOKENS >= dec->cfg.max_seq_len,
+                  "decoder_prefill_paged: max_pages * %d must cover max_seq_len %d", LLMIE_KV_PAGE_TOKENS, dec->cfg.max_seq_len);
+    dec->page_table = block_table;
+    dec->max_pages = max_pages;
+    dec->num_pages = num_pages;
+    const int rc = llmie_decoder_prefill(dec, hidden_in, hidden_out, k_pool, v_pool, input_lengths, history_lengths, batch, num_tokens,
+                                         max_q_len, workspace, workspace_bytes, stream);
+    dec->page_table = nullptr;
+    dec->max_pages = dec->num_pages = 0;
+    return rc;
 }
 
 extern "C" int llmie_lm_head_sample(llmie_decoder *dec, void *hidden, const void *final_norm_gamma,

@@ -74,6 +74,7 @@ int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, void *k_cache, vo
                           const int32_t *cum_seqlens, const int32_t *history_len, const float2 *rope, int layer, int batch,
                           int num_tokens, int max_q_len, int head_num, int kv_head_num, int head_size, int max_seq_len,
                           int rotary_dim, hipStream_t st, int kv_fp8 = 0 /* caches are e4m3 bytes */, float k_scale = 1.f,
-                          float v_scale = 1.f);
+                          float v_scale = 1.f, const int32_t *block_table = nullptr /* paged cache, see decoder_mha_rope */,
+                          int max_pages = 0, int num_pages = 0);
 
 }  // namespace llmie

@@ -36,7 +36,9 @@ __global__ __launch_bounds__(256) void prefill_rope_append_kernel(half_t *__rest
                                                                   const int32_t *__restrict__ cum, const int32_t *__restrict__ hist,
                                                                   const float2 *__restrict__ rope, int batch, int head_num,
                                                                   int kv_head_num, int max_seq_len, int rotary_dim, size_t layer_off,
-                                                                  float k_inv_scale, float v_inv_scale) {
+                                                                  float k_inv_scale, float v_inv_scale,
+                                                                  const int32_t *__restrict__ table /* paged cache or null */,
+                                                                  int max_pages) {
     const int t = blockIdx.x;
     int b, pos;
     locate_token(cum, batch, t, b, pos);
@@ -78,7 +80,9 @@ __global__ __launch_bounds__(256) void prefill_rope_append_kernel(half_t *__rest
         } else {
             const bool is_k = h < head_num + kv_head_num;
             const int g = is_k ? h - head_num : h - head_num - kv_head_num;
-            const size_t off = layer_off + ((static_cast<size_t>(b) * kv_head_num + g) * max_seq_len + tpos) * HS;
+            // dense [bs, kvh, max_seq, hs] slab, or 128-token pages [num_pages, kvh, 128, hs] through the block table
+            const size_t off = table ? layer_off + ((static_cast<size_t>(table[static_cast<size_t>(b) * max_pages + tpos / 128]) * kv_head_num + g) * 128 + tpos % 128) * HS
+                                     : layer_off + ((static_cast<size_t>(b) * kv_head_num + g) * max_seq_len + tpos) * HS;
             if constexpr (KV8) {
                 // quantise the fp16-rounded value (what the fp16 cache would hold), as the decode kernel does
                 uint8_t *dst = static_cast<uint8_t *>(is_k ? k_cache : v_cache) + off;
@@ -106,7 +110,8 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
                                                             const void *__restrict__ v_cache, half_t *__restrict__ out,
                                                             const int32_t *__restrict__ cum, const int32_t *__restrict__ hist,
                                                             int head_num, int kv_head_num, int max_seq_len, size_t layer_off,
-                                                            float k_scale, float v_scale) {
+                                                            float k_scale, float v_scale,
+                                                            const int32_t *__restrict__ table /* paged cache or null */, int max_pages) {
     static_assert(HS == 128, "tuned for head_size 128");
     // V rows are 288 bytes (256 + 32): the PV operand is fetched with ds_read_b64_tr_b16 (gfx950 transposed LDS read: a 16-lane
     // group reads a block of 4 keys x 16 head dims and every lane receives one column of it = 4 consecutive keys of its head
@@ -138,9 +143,15 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
     for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const half8_t *>(qptr + 32 * s + 8 * q);
     const int qpos = history + qrow_c;  // keys t <= qpos are visible
 
-    const size_t head_off = layer_off + (static_cast<size_t>(b) * kv_head_num + g) * max_seq_len * HS;
-    const half_t *kc = static_cast<const half_t *>(k_cache) + head_off, *vc = static_cast<const half_t *>(v_cache) + head_off;
-    const uint8_t *kc8 = static_cast<const uint8_t *>(k_cache) + head_off, *vc8 = static_cast<const uint8_t *>(v_cache) + head_off;
+    // element offset of key row t of this (sequence, kv head): dense slab, or the 128-token page of the block table (a 64-key
+    // tile never crosses a page; the lookup happens where the tile is FETCHED, two iterations before it is used)
+    auto row_off = [&](int t) -> size_t {
+        if (table)
+            return layer_off + ((static_cast<size_t>(table[static_cast<size_t>(b) * max_pages + t / 128]) * kv_head_num + g) * 128 + t % 128) * HS;
+        return layer_off + ((static_cast<size_t>(b) * kv_head_num + g) * max_seq_len + t) * HS;
+    };
+    const half_t *kc = static_cast<const half_t *>(k_cache), *vc = static_cast<const half_t *>(v_cache);
+    const uint8_t *kc8 = static_cast<const uint8_t *>(k_cache), *vc8 = static_cast<const uint8_t *>(v_cache);
     (void)kc; (void)vc; (void)kc8; (void)vc8;
 
     floatx4 o[8];  // O^T tiles: rows d = 16*dt + 4q + e, col = this lane's query row
@@ -159,11 +170,11 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
             const int id = tid + NTHR * i, row = id >> 4, ch = id & 15;
             const int t = min(t0 + row, ctx - 1);
             if constexpr (KV8) {
-                kreg8[i] = *reinterpret_cast<const uint2 *>(kc8 + static_cast<size_t>(t) * HS + ch * 8);
-                vreg8[i] = *reinterpret_cast<const uint2 *>(vc8 + static_cast<size_t>(t) * HS + ch * 8);
+                kreg8[i] = *reinterpret_cast<const uint2 *>(kc8 + row_off(t) + ch * 8);
+                vreg8[i] = *reinterpret_cast<const uint2 *>(vc8 + row_off(t) + ch * 8);
             } else {
-                kreg[i] = *reinterpret_cast<const half8_t *>(kc + static_cast<size_t>(t) * HS + ch * 8);
-                vreg[i] = *reinterpret_cast<const half8_t *>(vc + static_cast<size_t>(t) * HS + ch * 8);
+                kreg[i] = *reinterpret_cast<const half8_t *>(kc + row_off(t) + ch * 8);
+                vreg[i] = *reinterpret_cast<const half8_t *>(vc + row_off(t) + ch * 8);
             }
         }
     };
@@ -295,12 +306,14 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
 int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, void *k_cache, void *v_cache, half_t *out,
                           const int32_t *cum_seqlens, const int32_t *history_len, const float2 *rope, int layer, int batch,
                           int num_tokens, int max_q_len, int head_num, int kv_head_num, int head_size, int max_seq_len,
-                          int rotary_dim, hipStream_t st, int kv_fp8, float k_scale, float v_scale) {
+                          int rotary_dim, hipStream_t st, int kv_fp8, float k_scale, float v_scale, const int32_t *block_table,
+                          int max_pages, int num_pages) {
     if (head_size != 128) {
         set_error("prefill attention: head_size %d not supported by the flash kernel (128 only)", head_size);
         return LLMIE_ERR_UNSUPPORTED;
     }
-    const size_t layer_off = static_cast<size_t>(layer) * batch * kv_head_num * max_seq_len * head_size;
+    const size_t layer_off = block_table ? static_cast<size_t>(layer) * num_pages * kv_head_num * 128 * head_size
+                                         : static_cast<size_t>(layer) * batch * kv_head_num * max_seq_len * head_size;
     static const int nw = getenv("LLMIE_PF_NW") ? atoi(getenv("LLMIE_PF_NW")) : 8;  // waves per workgroup (x 16 query rows)
     const int bq = (nw == 4 ? 4 : 8) * 16;
     dim3 grid((max_q_len + bq - 1) / bq, head_num, batch);
@@ -308,14 +321,14 @@ int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, void *k_cache, vo
     if (kv_fp8)
         prefill_rope_append_kernel<128, true><<<num_tokens, 256, 0, st>>>(qkv, qkv_bias, k_cache, v_cache, cum_seqlens, history_len,
                                                                           rope, batch, head_num, kv_head_num, max_seq_len,
-                                                                          rotary_dim, layer_off, 1.0f / ks, 1.0f / vs);
+                                                                          rotary_dim, layer_off, 1.0f / ks, 1.0f / vs, block_table, max_pages);
     else
         prefill_rope_append_kernel<128, false><<<num_tokens, 256, 0, st>>>(qkv, qkv_bias, k_cache, v_cache, cum_seqlens, history_len,
                                                                            rope, batch, head_num, kv_head_num, max_seq_len,
-                                                                           rotary_dim, layer_off, 1.f, 1.f);
+                                                                           rotary_dim, layer_off, 1.f, 1.f, block_table, max_pages);
 #define LLMIE_FLASH(KV8_, NW_)                                                                                                  \
     prefill_flash_kernel<128, KV8_, NW_><<<grid, NW_ * 64, 0, st>>>(qkv, k_cache, v_cache, out, cum_seqlens, history_len, head_num, \
-                                                                    kv_head_num, max_seq_len, layer_off, ks, vs)
+                                                                    kv_head_num, max_seq_len, layer_off, ks, vs, block_table, max_pages)
     if (kv_fp8) {
         if (nw == 4) LLMIE_FLASH(true, 4);
         else LLMIE_FLASH(true, 8);

@@ -63,3 +63,48 @@ def test_paged_decode_is_bit_identical_to_dense(llmie, name, nh, kvh, hs, I, L, 
     again = dec.forward_paged(x, torch.empty_like(x), kp, vp, perm, -1, step_dev=step_dev)
     assert torch.equal(again, dense_out)
     dec.close()
+
+
+@pytest.mark.parametrize("name,nh,kvh,hs,I,L,lens,hist,max_seq,kv8", [
+    ("b1_s300", 8, 8, 128, 1024, 2, [300], [0], 384, False), ("ragged_b3_gqa", 16, 4, 128, 1024, 2, [70, 257, 129], [0, 0, 0], 384, False),
+    ("history_chunks", 8, 8, 128, 768, 2, [100, 64], [150, 200], 384, False), ("fp8kv_b2", 8, 8, 128, 768, 2, [200, 131], [0, 0], 256, True),
+    ("equal_b2_then_decode", 8, 8, 128, 512, 1, [140, 140], [0, 0], 256, False)])
+def test_paged_prefill_is_bit_identical_to_dense(llmie, name, nh, kvh, hs, I, L, lens, hist, max_seq, kv8):
+    """llmie_decoder_prefill_paged == llmie_decoder_prefill (hidden states and every cache row), then one decode step on
+    the pages it wrote == the dense decode step."""
+    rng = np.random.default_rng(72)
+    bs, T, H = len(lens), sum(lens), nh * hs
+    dec = _engine(llmie, rng, nh, kvh, hs, I, L, max_seq, bs, kv8)
+    cdt = torch.uint8 if kv8 else F16
+    kd = torch.zeros((L, bs, kvh, max_seq, hs), dtype=cdt, device=DEV)
+    vd = torch.zeros_like(kd)
+    max_pages = (max_seq + 127) // 128
+    num_pages = bs * max_pages + 2
+    perm = torch.from_numpy(rng.permutation(num_pages)[:bs * max_pages].astype(np.int32)).reshape(bs, max_pages).to(DEV)
+    kp = torch.zeros((L, num_pages, kvh, 128, hs), dtype=cdt, device=DEV)
+    vp = torch.zeros_like(kp)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)
+    if any(hist):  # history: prefill the earlier chunk on both layouts first (dense call for dense, paged call for pages)
+        xh = torch.randn((sum(hist), H), device=DEV).to(F16)
+        a = dec.prefill(xh, torch.empty_like(xh), kd, vd, i32(hist), i32([0] * bs), max(hist)).clone()
+        b = dec.prefill_paged(xh, torch.empty_like(xh), kp, vp, perm, i32(hist), i32([0] * bs), max(hist))
+        assert torch.equal(a, b)
+    x = torch.randn((T, H), device=DEV).to(F16)
+    dense_out = dec.prefill(x, torch.empty_like(x), kd, vd, i32(lens), i32(hist), max(lens)).clone()
+    paged_out = dec.prefill_paged(x, torch.empty_like(x), kp, vp, perm, i32(lens), i32(hist), max(lens))
+    assert torch.equal(paged_out, dense_out)
+    tot = [a + b for a, b in zip(lens, hist)]
+    kback, vback = torch.zeros_like(kd), torch.zeros_like(vd)
+    llmie.kv_pages_copy(kback, kp, perm, i32(tot), False)
+    llmie.kv_pages_copy(vback, vp, perm, i32(tot), False)
+    for b in range(bs):
+        assert torch.equal(kback[:, b, :, :tot[b]], kd[:, b, :, :tot[b]]) and torch.equal(vback[:, b, :, :tot[b]], vd[:, b, :, :tot[b]])
+    used = torch.zeros(num_pages, dtype=torch.bool, device=DEV)
+    used[perm.flatten().long()] = True
+    assert int(kp[:, ~used].float().abs().sum().item()) == 0
+    if len(set(tot)) == 1:  # the decode engine takes one step index for the batch
+        xs = torch.randn((bs, H), device=DEV).to(F16)
+        d = dec.forward(xs, torch.empty_like(xs), kd, vd, tot[0] + 1).clone()
+        p = dec.forward_paged(xs, torch.empty_like(xs), kp, vp, perm, tot[0] + 1)
+        assert torch.equal(d, p)
+    dec.close()
