@@ -1,0 +1,148 @@
+// Split-K MFMA GEMM for 64 < M <= 128 activation rows (decode batches of 65..128 sequences, 128-token prefills):
+//   slab[ks][m][n] = sum_{k in slice ks} X[m,k] * W[n,k]        (fp32 partials, consumed like skinny_splitk_kernel's)
+// -- the linear of launchLinearGemm (linear.cu:10-87) where the weight stream still bounds the op (128 flop per weight
+// byte) but the 64-row skinny kernel re-stages the 128-row activation tile through VGPRs once per 64 weight rows (L2
+// activation traffic = 2x the weight stream, one barrier pair per 128 k: measured 2.2-2.4 TB/s at M = 128).
+// Here a 512-thread workgroup multiplies ALL (<= 128) activation rows with 64*WN weight rows over one K slice:
+//   * both operands go HBM/L2 -> LDS by global_load_lds_dwordx4 (no VGPR staging, no ds_write); the XOR swizzle that makes
+//     fragment reads conflict-free is applied on the source address (as in gemm256.cuh);
+//   * NS-stage ring with COUNTED waits: tile kt+NS-1 is issued while tile kt is multiplied, s_waitcnt vmcnt leaves the
+//     younger tiles in flight across the one barrier per k-tile, so NS-1 tiles (2 x 32 KiB of weights at WN = 4) are in
+//     flight per CU -- what a bandwidth-bound stream needs;
+//   * 8 waves as 2 (M) x 4 (N), wave tile 64 x 16*WN: L2 activation traffic = |X| per 64*WN weight rows (0.5x the weight stream).
+// LDS stage: X (128 rows x 128 B) | W half 0 | [W half 1], 16 KiB each.
+#pragma once
+#include "device_utils.cuh"
+
+namespace llmie {
+
+typedef int mid_intx8 __attribute__((ext_vector_type(8)));
+
+template <bool FP8, int WN, int NS>
+__global__ __launch_bounds__(512) void mid_splitk_kernel(const void *__restrict__ Xv, const void *__restrict__ Wv,
+                                                         float *__restrict__ slab, int M, int N, int K, int KS, int kt_per_slice) {
+    constexpr int ES = FP8 ? 1 : 2;   // bytes per element
+    constexpr int BK = 128 / ES;      // k per tile: rows of 128 bytes either way
+    constexpr int NHALF = 1 + WN / 2; // 128-row halves per stage: X, W0, [W1]
+    constexpr int HALF_BYTES = 128 * 128, STAGE_BYTES = NHALF * HALF_BYTES;
+    constexpr int IPT = 2 * NHALF;    // LDS-DMA instructions per wave per k-tile
+    static_assert(WN == 2 || WN == 4, "128 or 256 weight rows per workgroup");
+    static_assert(NS >= 2 && (NS - 2) * IPT < 64, "vmcnt is a 6-bit counter");
+    const unsigned char *X = static_cast<const unsigned char *>(Xv), *W = static_cast<const unsigned char *>(Wv);
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int r = lane & 15, q = lane >> 4;
+    const int tile = blockIdx.x / KS, ks = blockIdx.x - tile * KS;
+    const int n0 = tile * 64 * WN;
+    const int KT = K / BK;
+    const int kt0 = ks * kt_per_slice, nk = min(KT, kt0 + kt_per_slice) - kt0;  // host: every slice has >= 1 k-tile
+
+    // DMA plan (gemm256.cuh): half h, instruction i: this wave fills rows (i*8 + wave)*8 .. +8; lane -> row + lane/8,
+    // LDS slot lane%8 receives source chunk slot ^ (row & 7)
+    const unsigned char *src[NHALF][2];
+#pragma unroll
+    for (int h = 0; h < NHALF; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (i * 8 + wave) * 8 + (lane >> 3), slot = lane & 7, chunk = slot ^ (row & 7);
+            const int grow = h == 0 ? min(row, M - 1) : min(n0 + (h - 1) * 128 + row, N - 1);  // clamped rows are never stored
+            src[h][i] = (h == 0 ? X : W) + (static_cast<size_t>(grow) * K + static_cast<size_t>(kt0) * BK) * ES + chunk * 16;
+        }
+    // Workgroups of one K slice run in lock step and a k-tile of 128-byte row pieces at an 8 KiB row pitch lands in ONE L2
+    // channel: every workgroup starts its slice at a different k-tile (sum order is irrelevant: fp32 partials), so that the
+    // concurrent tiles spread over the channels.
+    const int rot = nk > 0 ? (tile * 3 + ks) % nk : 0;
+    auto dma_tile = [&](int tt, int stage) {
+        const int t = tt + rot < nk ? tt + rot : tt + rot - nk;
+#pragma unroll
+        for (int h = 0; h < NHALF; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                unsigned char *dst = lds + stage * STAGE_BYTES + h * HALF_BYTES + (i * 8 + wave) * 1024;  // wave-uniform
+                typedef const __attribute__((address_space(1))) void *gptr_t;
+                typedef __attribute__((address_space(3))) void *lptr_t;
+                __builtin_amdgcn_global_load_lds((gptr_t)(src[h][i] + static_cast<size_t>(t) * 128), (lptr_t)dst, 16, 0, 0);
+            }
+    };
+
+    floatx4 acc[4][WN];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int wcol = wc * 16 * WN;  // first weight row of this wave inside the workgroup tile
+    const int a_row0 = wr * 64 + r, b_row0 = (wcol & 127) + r;
+    const unsigned char *a_base = lds, *b_base = lds + (1 + (wcol >> 7)) * HALF_BYTES;
+    auto frag = [&](const unsigned char *base, int row, int c) {
+        return *reinterpret_cast<const half8_t *>(base + row * 128 + ((c ^ (row & 7)) << 4));
+    };
+    auto frag8 = [&](const unsigned char *base, int row) {  // fp8: lane (r, q) supplies k bytes [32q, 32q + 32) of its row
+        const uint4_t lo = *reinterpret_cast<const uint4_t *>(base + row * 128 + (((2 * q) ^ (row & 7)) << 4));
+        const uint4_t hi = *reinterpret_cast<const uint4_t *>(base + row * 128 + (((2 * q + 1) ^ (row & 7)) << 4));
+        return mid_intx8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+    };
+
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < nk) dma_tile(t, t);
+    int stage = 0, fill = NS - 1;  // fill = stage that receives tile kt + NS - 1
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed when at most the (NS - 2) younger tiles of this wave are outstanding
+        if (kt + NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * IPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave's part of tile kt landed; every wave is done with stage `fill` (tile kt - 1)
+        if (kt + NS - 1 < nk) dma_tile(kt + NS - 1, fill);
+        const unsigned char *ab = a_base + stage * STAGE_BYTES, *bb = b_base + stage * STAGE_BYTES;
+        if constexpr (FP8) {
+            mid_intx8 bf[WN], af[4];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bf[j] = frag8(bb, b_row0 + j * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = frag8(ab, a_row0 + i * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[j], af[i], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0,
+                                                                                 0x7F7F7F7F);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                half8_t bf[WN], af[4];
+#pragma unroll
+                for (int j = 0; j < WN; ++j) bf[j] = frag(bb, b_row0 + j * 16, s * 4 + q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = frag(ab, a_row0 + i * 16, s * 4 + q);
+                // D[n-row, m-col]: W as the MFMA A operand -> 4 consecutive n per lane (16-byte fp32 stores)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        stage = stage + 1 == NS ? 0 : stage + 1;
+        fill = fill + 1 == NS ? 0 : fill + 1;
+    }
+    // acc[i][j]: lane holds rows m = wr*64 + i*16 + r, columns n0 + wcol + j*16 + 4q + e
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = wr * 64 + i * 16 + r;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int n = n0 + wcol + j * 16 + 4 * q;
+            float *dst = slab + (static_cast<size_t>(ks) * M + m) * N + n;
+            if (n + 3 < N && (N & 3) == 0) {
+                *reinterpret_cast<floatx4 *>(dst) = acc[i][j];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < N) dst[e] = acc[i][j][e];
+            }
+        }
+    }
+}
+
+}  // namespace llmie

@@ -1,6 +1,7 @@
 // llmie_linear / llmie_batched_gemm: shape dispatch over the kernels in gemm_kernels.cuh.
 #include "gemm_kernels.cuh"
 #include "gemm256.cuh"
+#include "gemm_mid.cuh"
 #include "llmie_internal.h"
 
 #include <cstdlib>
@@ -233,6 +234,46 @@ int linear_splitk_partial(int wbits, const void *x, const void *W, int M, int K,
         (wbits != 16 && wbits != 8 && wbits != 4 && wbits != WF_FP8)) {
         set_error("linear(split-K): unsupported shape M=%d K=%d (bits=%d)", M, K, wbits);
         return LLMIE_ERR_UNSUPPORTED;
+    }
+    // 64 < M <= 128, fp16 or e4m3 operands: 128-row LDS-DMA kernel (gemm_mid.cuh)
+    static const int mid_min_m = env_int("LLMIE_MID_MIN_M", 65);
+    if ((wbits == 16 || wbits == WF_FP8) && M >= mid_min_m && K % 128 == 0 && N >= 128) {
+        static const int mid_wgs = env_int("LLMIE_MID_WGS", 256), mid_maxks = env_int("LLMIE_MID_MAXKS", 8);
+        static const int mid_wide_n = env_int("LLMIE_MID_WIDE_N", 8192);  // N >= this: 256 weight rows per workgroup
+        const bool fp8 = wbits == WF_FP8;
+        const int wn = N >= mid_wide_n ? 4 : 2;
+        const int mtiles = (N + 64 * wn - 1) / (64 * wn), KT = K / (fp8 ? 128 : 64);
+        int ks = mid_wgs / mtiles;
+        ks = ks < 1 ? 1 : (ks > mid_maxks ? mid_maxks : ks);
+        if (ks > KT / 4) ks = KT / 4 > 0 ? KT / 4 : 1;
+        const int per = (KT + ks - 1) / ks;
+        ks = (KT + per - 1) / per;  // every slice non-empty
+        float *mslab = splitk_scratch(static_cast<size_t>(ks) * M * N);
+        if (!mslab) {
+            set_error("linear: split-K scratch allocation failed");
+            return LLMIE_ERR_WORKSPACE;
+        }
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<false, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 16384);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<true, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 16384);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<false, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 16384);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<true, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 16384);
+            attr_set = true;
+        }
+        const dim3 mgrid(mtiles * ks);
+        if (wn == 4) {
+            if (fp8) mid_splitk_kernel<true, 4, 3><<<mgrid, 512, 3 * 3 * 16384, st>>>(x, W, mslab, M, N, K, ks, per);
+            else mid_splitk_kernel<false, 4, 3><<<mgrid, 512, 3 * 3 * 16384, st>>>(x, W, mslab, M, N, K, ks, per);
+        } else {
+            if (fp8) mid_splitk_kernel<true, 2, 4><<<mgrid, 512, 4 * 2 * 16384, st>>>(x, W, mslab, M, N, K, ks, per);
+            else mid_splitk_kernel<false, 2, 4><<<mgrid, 512, 4 * 2 * 16384, st>>>(x, W, mslab, M, N, K, ks, per);
+        }
+        out->slab = mslab;
+        out->KS = ks;
+        out->M = M;
+        out->N = N;
+        return launch_status("linear(split-K 128-row)");
     }
     const int tiles = (N + 63) / 64, total_blocks = (K + bk - 1) / bk;
     static const int target = env_int("LLMIE_SPLITK_TARGET_WGS", 512);
