@@ -409,6 +409,39 @@ def main():
         for b in (32, 128):
             record("decode_f16_b%d_ctx512" % b, "f16", weights["layers"], b, 512, 2.0)
         out["extra"] = extra
+
+        # ---- the peak constants used above, with on-box measurements beside them: a device copy, and the
+        #      vendor library GEMM (torch.matmul = hipBLASLt/rocBLAS) next to this library's GEMM at the same prefill shape
+        def timed(fn, reps):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) * 1e-3 / reps
+
+        peaks = dict(hbm_GBs_datasheet=HBM_PEAK_GBS, mfma_f16_TFLOPs_datasheet=2500.0, mfma_fp8_TFLOPs_datasheet=5000.0)
+        try:
+            src = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+            dst = torch.empty_like(src)
+            peaks["measured_copy_GBs"] = round(2 * src.numel() / timed(lambda: dst.copy_(src), 10) / 1e9, 1)  # read + write
+            del src, dst
+            Mg, Ng, Kg = 4096, 12288, 4096
+            xa = torch.randn((Mg, Kg), device="cuda").half()
+            wa = (torch.randn((Ng, Kg), device="cuda") / 64).half()
+            ya = torch.empty((Mg, Ng), device="cuda", dtype=torch.float16)
+            fl = 2.0 * Mg * Ng * Kg
+            peaks["gemm_shape"] = [Mg, Ng, Kg]
+            peaks["measured_vendor_gemm_f16_TFLOPs"] = round(fl / timed(lambda: torch.matmul(xa, wa.t(), out=ya), 10) / 1e12, 1)
+            peaks["llmie_gemm_f16_TFLOPs"] = round(fl / timed(lambda: llmie.linear(xa, wa, ya), 10) / 1e12, 1)
+            del xa, wa, ya
+            torch.cuda.empty_cache()
+        except Exception as e:  # a side measurement must never take the bench line down
+            peaks["error"] = str(e)[:200]
+        out["peaks"] = peaks
     if args.layers:
         out["config"]["INVALID_debug_layers"] = args.layers
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -218,6 +218,18 @@ def test_linear(llmie, dtype, M, K, N, trans_b):
     close(host(y), exp, *tol(dtype, f32=(1e-4, 2e-5), f16=(2e-3, 2e-3)))
 
 
+@pytest.mark.parametrize("M,K,N", [(128, 4096, 12288), (100, 11008, 4096), (96, 4096, 8200), (77, 1024, 8194), (128, 512, 130),
+                                   (65, 4096, 22016), (200, 2048, 8448)])
+def test_linear_128_row_splitk(llmie, M, K, N):
+    """64 < M <= 128 rows per pass take the LDS-DMA split-K kernel (gemm_mid.cuh): 256- and 128-row weight tiles, ragged K
+    slices (64 k-tiles over 5 slices), ragged N tiles, N % 4 != 0 (scalar slab stores), clamped activation rows, two passes"""
+    rng = np.random.default_rng(M + N)
+    x, w = rnd(rng, (M, K), 1.0, torch.float16), rnd(rng, (N, K), 1.0 / np.sqrt(K), torch.float16)
+    y = torch.full((M, N), 99.0, dtype=torch.float16, device=DEV)
+    llmie.linear(dev(x, torch.float16), dev(w, torch.float16), y)
+    close(host(y), orc.linear(x, w), 2e-3, 2e-3)
+
+
 @pytest.mark.parametrize("M,K,N,epi", [(4096, 128, 3072, False), (4000, 192, 3100, False), (3900, 256, 3330, True),
                                        (8192, 64, 2048, True), (4096, 192, 1664, False), (4090, 128, 1602, True)])
 def test_linear_gemm256(llmie, M, K, N, epi):
