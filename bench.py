@@ -381,6 +381,15 @@ def main():
             del kc, vc, hid
             torch.cuda.empty_cache()
 
+        if os.environ.get("LLMIE_BENCH_SMALL_BATCH_SWEEP"):  # development: small-batch decode over the weight formats
+            for fmt_, wb_ in (("f16", 2.0), ("int8", 1.0), ("fp8", 1.0), ("int4", 0.5 + 2.0 / 128)):
+                ql = weights["layers"] if fmt_ == "f16" else quantize_layers(torch, llmie, weights["layers"], fmt_)
+                for b in (2, 3, 4, 6, 8):
+                    record("decode_%s_b%d_ctx512" % (fmt_, b), fmt_, ql, b, 512, wb_)
+                del ql
+                torch.cuda.empty_cache()
+            print(json.dumps({k: v["tokens_per_s"] for k, v in extra.items()}), flush=True)
+            return
         record_prefill("prefill_f16_b1_s2048", 1, 2048)
         record_prefill("prefill_f16_b8_s512", 8, 512)
         record_prefill("prefill_f16_b1_s128", 1, 128)   # BASELINE configs[1] shape (all 32 layers)
@@ -399,7 +408,7 @@ def main():
         del q4
         torch.cuda.empty_cache()
         q8f = quantize_layers(torch, llmie, weights["layers"], "fp8")   # BASELINE configs[4]: fp8 batch sweep at ctx 512
-        for b in (1, 32, 128):
+        for b in (1, 2, 4, 8, 16, 32, 64, 128):
             record("decode_fp8_b%d_ctx512" % b, "fp8", q8f, b, 512, 1.0)
         record("decode_fp8_b128_ctx512_kvfp8", "fp8", q8f, 128, 512, 1.0, True)   # e4m3 weights + e4m3 KV cache
         record_prefill("prefill_fp8_b8_s512", 8, 512, "fp8", q8f)

@@ -328,8 +328,18 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
     const bool fp8 = c.wfmt == LLMIE_W_FP8;
     const int kv8 = c.kv_fmt == LLMIE_KV_FP8;
     const float k_scale = c.k_scale > 0.f ? c.k_scale : 1.f, v_scale = c.v_scale > 0.f ? c.v_scale : 1.f;
-    const bool gemv_ok = wbits == 16 ? gemv_f16_eligible(batch, H, h, dec->layers[0].qkv.data)
-                                     : ((wbits != 0 || fp8) && ksplit_eligible(batch, H, fp8 ? 8 : wbits));
+    // GEMV form up to LLMIE_GEMV_MAX_BATCH rows (its dot products are VALU work that grows with the batch), MFMA split-K above
+    static const int gemv_max_env = getenv("LLMIE_GEMV_MAX_BATCH") ? atoi(getenv("LLMIE_GEMV_MAX_BATCH")) : -1;
+    // measured crossover on MI355X (7B, ctx 512, tokens/s GEMV vs split-K): fp16 b4 1157/1143, b6 1496/1592; int8 b4 1416/1404,
+    // b6 1672/1962; fp8 b3 947/944, b4 1127/1213; int4 b2 796/745, b3 896/1074
+    const int gemv_max = gemv_max_env >= 0 ? gemv_max_env : (fp8 ? 3 : (wbits == 4 ? 2 : 4));
+    static const int batch_fused_off = getenv("LLMIE_NO_FUSED_BATCH") ? 1 : 0;
+    const bool int4_ok = wbits == 4 && c.int4_group == 128 && batch <= 64;  // int4 MFMA form: group-128 scales, 64 rows per pass
+    const bool batch_path_ok = !batch_fused_off && c.dtype == LLMIE_F16 && (wbits == 16 || wbits == 8 || int4_ok || fp8) && hs_ok &&
+                               rep_ok && batch <= 128 && H % 256 == 0 && I % 256 == 0 && H >= 512 && I >= 512 && splitk_rownorm_eligible(H);
+    const bool gemv_ok = (batch <= gemv_max || !batch_path_ok) &&
+                         (wbits == 16 ? gemv_f16_eligible(batch, H, h, dec->layers[0].qkv.data)
+                                      : ((wbits != 0 || fp8) && ksplit_eligible(batch, H, fp8 ? 8 : wbits)));
     if (!fused_off && c.dtype == LLMIE_F16 && (wbits != 0 || fp8) && hs_ok && rep_ok && H % 8 == 0 && gemv_ok) {
         hipStream_t st = as_stream(stream);
         // In-launch merge of the attention partials (ticket + agent-scope release/acquire) measured SLOWER than the
@@ -389,10 +399,7 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
     // (each small dependent launch costs ~4.5 us on MI355X, a third of a batch-32 int8 layer before this fusion)
     // fp8: activations enter every projection as per-token e4m3; the row kernel emits them directly for the qkv and
     // gate_up inputs, the attention and SwiGLU outputs take a quantize_rows launch each (10 launches per layer).
-    static const int batch_fused_off = getenv("LLMIE_NO_FUSED_BATCH") ? 1 : 0;
-    const bool int4_ok = wbits == 4 && c.int4_group == 128 && batch <= 64;  // int4 MFMA form: group-128 scales, 64 rows per pass
-    if (!batch_fused_off && c.dtype == LLMIE_F16 && (wbits == 16 || wbits == 8 || int4_ok || fp8) && hs_ok && rep_ok && batch <= 128 &&
-        H % 256 == 0 && I % 256 == 0 && H >= 512 && I >= 512 && splitk_rownorm_eligible(H)) {
+    if (batch_path_ok) {
         hipStream_t st = as_stream(stream);
         half_t *hh = static_cast<half_t *>(h), *resid = reinterpret_cast<half_t *>(dec->resid);
         half_t *mha = reinterpret_cast<half_t *>(dec->mha), *act = reinterpret_cast<half_t *>(dec->act);
