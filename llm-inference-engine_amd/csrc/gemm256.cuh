@@ -32,7 +32,10 @@ template <bool FP8, bool HAS_EPI, int WN = 4, bool SWIGLU = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(const void *__restrict__ Xv, const void *__restrict__ Wv, half_t *C,
                                                       int M, int N, int K, const half_t *__restrict__ bias,
                                                       const half_t *residual, int tiles_n, const float *__restrict__ xscale,
-                                                      const float *__restrict__ wscale) {
+                                                      const float *__restrict__ wscale, int ldc_arg = 0) {
+    // ldc_arg != 0: C (and residual) rows are ldc_arg elements apart -- a launch over a column range [n_begin, n_begin + N)
+    // of a wider output, with W / bias / wscale / C / residual pointers already advanced to n_begin
+    const size_t ldc = ldc_arg ? ldc_arg : N;
     constexpr int ES = FP8 ? 1 : 2;            // bytes per element
     constexpr int BK = 128 / ES;               // k per tile: rows of 128 bytes either way
     static_assert(!SWIGLU || (WN == 4 && !HAS_EPI), "SwiGLU form: 256 weight rows = 128 gate + 128 up, no bias/residual");
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const void *__restrict__ X
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             const int n = n0 + wcol + j * 16 + 4 * q;
-            if (n + 3 < N && (N & 3) == 0) {
+            if (n + 3 < N && (N & 3) == 0 && (ldc & 3) == 0) {
                 floatx4 v = acc[i][j];
                 if constexpr (FP8) {
                     const floatx4 ws = *reinterpret_cast<const floatx4 *>(wscale + n);
@@ -206,13 +209,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const void *__restrict__ X
                         for (int e = 0; e < 4; ++e) v[e] += to_f32(b4[e]);
                     }
                     if (residual) {
-                        const half4_t r4 = *reinterpret_cast<const half4_t *>(residual + static_cast<size_t>(m) * N + n);
+                        const half4_t r4 = *reinterpret_cast<const half4_t *>(residual + static_cast<size_t>(m) * ldc + n);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += to_f32(r4[e]);
                     }
                 }
                 const half4_t o = {from_f32<half_t>(v[0]), from_f32<half_t>(v[1]), from_f32<half_t>(v[2]), from_f32<half_t>(v[3])};
-                *reinterpret_cast<half4_t *>(C + static_cast<size_t>(m) * N + n) = o;
+                *reinterpret_cast<half4_t *>(C + static_cast<size_t>(m) * ldc + n) = o;
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -221,9 +224,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const void *__restrict__ X
                         if constexpr (FP8) v *= wscale[n + e] * xscale[m];
                         if (HAS_EPI) {
                             if (bias) v += to_f32(bias[n + e]);
-                            if (residual) v += to_f32(residual[static_cast<size_t>(m) * N + n + e]);
+                            if (residual) v += to_f32(residual[static_cast<size_t>(m) * ldc + n + e]);
                         }
-                        C[static_cast<size_t>(m) * N + n + e] = from_f32<half_t>(v);
+                        C[static_cast<size_t>(m) * ldc + n + e] = from_f32<half_t>(v);
                     }
             }
         }

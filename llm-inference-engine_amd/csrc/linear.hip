@@ -488,7 +488,7 @@ bool gemm256_fills(int M, int N) { return gemm256_wn(M, N) != 0; }
 
 template <bool FP8, bool EPI, int WN>
 static void gemm256_launch_t(const void *x, const void *W, half_t *y, int M, int N, int K, const half_t *bias, const half_t *residual,
-                             const float *xscale, const float *wscale, hipStream_t st) {
+                             const float *xscale, const float *wscale, hipStream_t st, int ldc = 0) {
     constexpr int lds_bytes = 2 * (2 + WN / 2) * 128 * 128;
     static bool attr_set = false;
     if (!attr_set) {
@@ -497,7 +497,7 @@ static void gemm256_launch_t(const void *x, const void *W, half_t *y, int M, int
         attr_set = true;
     }
     const int tm = (M + 255) / 256, tn = (N + 64 * WN - 1) / (64 * WN);
-    gemm256_kernel<FP8, EPI, WN><<<tm * tn, 512, lds_bytes, st>>>(x, W, y, M, N, K, bias, residual, tn, xscale, wscale);
+    gemm256_kernel<FP8, EPI, WN><<<tm * tn, 512, lds_bytes, st>>>(x, W, y, M, N, K, bias, residual, tn, xscale, wscale, ldc);
 }
 
 // SwiGLU form: W = fused gate_up [2I, K], y = silu(x.Wg^T) * (x.Wu^T) [M, I]
@@ -524,13 +524,17 @@ void gemm256_swiglu_launch(bool fp8, const void *x, const void *W, half_t *y, in
         gemm256_kernel<false, false, 4, true><<<tm * tn, 512, lds_bytes, st>>>(x, W, y, M, two_inter, K, nullptr, nullptr, tn, nullptr, nullptr);
 }
 
-void gemm256_launch(bool fp8, const void *x, const void *W, half_t *y, int M, int N, int K, const half_t *bias,
-                    const half_t *residual, const float *xscale, const float *wscale, hipStream_t st) {
-    const int wn = gemm256_wn(M, N) == 2 ? 2 : 4;
+// One launch over the column range [nb, nb + n) of the [M, N] output with 64*wn-column tiles.
+static void gemm256_range(bool fp8, int wn, const void *x, const void *W, half_t *y, int M, int N, int K, const half_t *bias,
+                          const half_t *residual, const float *xscale, const float *wscale, hipStream_t st, int nb, int n) {
     const bool epi = bias || residual;
+    const void *Wr = static_cast<const unsigned char *>(W) + static_cast<size_t>(nb) * K * (fp8 ? 1 : 2);
+    half_t *yr = y + nb;
+    const half_t *br = bias ? bias + nb : nullptr, *rr = residual ? residual + nb : nullptr;
+    const float *wsr = wscale ? wscale + nb : nullptr;
 #define LLMIE_G256(F8_, EPI_)                                                                                          \
-    (wn == 4 ? gemm256_launch_t<F8_, EPI_, 4>(x, W, y, M, N, K, bias, residual, xscale, wscale, st)                    \
-             : gemm256_launch_t<F8_, EPI_, 2>(x, W, y, M, N, K, bias, residual, xscale, wscale, st))
+    (wn == 4 ? gemm256_launch_t<F8_, EPI_, 4>(x, Wr, yr, M, n, K, br, rr, xscale, wsr, st, N)                          \
+             : gemm256_launch_t<F8_, EPI_, 2>(x, Wr, yr, M, n, K, br, rr, xscale, wsr, st, N))
     if (fp8) {
         if (epi) LLMIE_G256(true, true);
         else LLMIE_G256(true, false);
@@ -539,6 +543,45 @@ void gemm256_launch(bool fp8, const void *x, const void *W, half_t *y, int M, in
         else LLMIE_G256(false, false);
     }
 #undef LLMIE_G256
+}
+
+// Tile plan by rounds of the 256 CUs (one 512-thread workgroup per CU): a 256 x 128 tile costs ~0.6 of a 256 x 256 tile
+// (measured: 0.96 vs 1.12 PFLOP/s on full rounds).  A half-empty last round of 256-wide tiles (qkv at 2048 tokens: 384
+// tiles = 1.5 rounds) is avoided by running the full rounds 256-wide and the remaining columns 128-wide in a second launch.
+void gemm256_launch(bool fp8, const void *x, const void *W, half_t *y, int M, int N, int K, const half_t *bias,
+                    const half_t *residual, const float *xscale, const float *wscale, hipStream_t st) {
+    static const int cus = env_int("LLMIE_GEMM256_CUS", 256);
+    static const bool no_split = getenv("LLMIE_GEMM256_NO_SPLIT") != nullptr;
+    const int tm = (M + 255) / 256, tn4 = (N + 255) / 256, tn2 = (N + 127) / 128;
+    const int tiles4 = tm * tn4, tiles2 = tm * tn2;
+    auto rounds = [&](int t) { return (t + cus - 1) / cus; };
+    const float narrow = 0.6f;
+    float best = static_cast<float>(rounds(tiles4));
+    int plan = 4;
+    if (gemm256_wn(M, N) == 2) {  // the 256-wide grid does not fill the chip (unchanged rule)
+        plan = 2;
+    } else if (!no_split && N % 4 == 0) {
+        if (rounds(tiles2) * narrow < best) {
+            best = rounds(tiles2) * narrow;
+            plan = 2;
+        }
+        const int a_tn = (tiles4 / cus) * cus / tm;  // 256-wide column tiles that make whole rounds
+        if (a_tn > 0 && a_tn < tn4) {
+            const int nB = N - a_tn * 256, tilesB = tm * ((nB + 127) / 128);
+            const float c = static_cast<float>(rounds(tm * a_tn)) + rounds(tilesB) * narrow;
+            if (c < best) {
+                best = c;
+                plan = 42;
+            }
+        }
+    }
+    if (plan == 42) {
+        const int a_tn = (tiles4 / cus) * cus / tm;
+        gemm256_range(fp8, 4, x, W, y, M, N, K, bias, residual, xscale, wscale, st, 0, a_tn * 256);
+        gemm256_range(fp8, 2, x, W, y, M, N, K, bias, residual, xscale, wscale, st, a_tn * 256, N - a_tn * 256);
+    } else {
+        gemm256_range(fp8, plan, x, W, y, M, N, K, bias, residual, xscale, wscale, st, 0, N);
+    }
 }
 
 int linear_f16_nk(const half_t *x, const half_t *W, half_t *y, int M, int K, int N, int epi,

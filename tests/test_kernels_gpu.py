@@ -231,10 +231,12 @@ def test_linear_128_row_splitk(llmie, M, K, N):
 
 
 @pytest.mark.parametrize("M,K,N,epi", [(4096, 128, 3072, False), (4000, 192, 3100, False), (3900, 256, 3330, True),
-                                       (8192, 64, 2048, True), (4096, 192, 1664, False), (4090, 128, 1602, True)])
+                                       (8192, 64, 2048, True), (4096, 192, 1664, False), (4090, 128, 1602, True),
+                                       (2048, 128, 12288, True), (2000, 192, 12200, False)])
 def test_linear_gemm256(llmie, M, K, N, epi):
     """shapes whose 256 x 256 grid fills the chip (>= 192 tiles) take the LDS-DMA kernel (gemm256.cuh): full tiles,
-    ragged M and N edges, odd k-tile counts, bias + in-place residual epilogue"""
+    ragged M and N edges, odd k-tile counts, bias + in-place residual epilogue; the last two shapes take the two-launch plan
+    (whole rounds of 256-wide tiles + the remaining columns 128-wide)"""
     rng = np.random.default_rng(M + N)
     x, w = rnd(rng, (M, K), 1.0, torch.float16), rnd(rng, (N, K), 1.0 / np.sqrt(K), torch.float16)
     if epi:
