@@ -576,6 +576,38 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
     // context_decoder.cpp:70: exclusive prefix of the lengths (padding offsets are a by-product nobody needs here);
     // the prefix kernel takes [batch, max_q_len] with max_q_len = ceil(T / batch) rows worth of scratch -> use 1 row of T
     if ((rc = llmie_cal_padding_offset(pad, cum, input_lengths, batch, (T + batch - 1) / batch, stream))) return rc;
+    // Short prefills (<= 128 tokens, fp16 weights) are weight-stream bound like a decode batch: same launch fusion as the batch
+    // decode path -- every projection leaves split-K slabs, the O and down slabs are consumed by the row kernel (reduction +
+    // residual stream + the next RMSNorm), the gate/up slabs by the SwiGLU finalize: 9 launches per layer instead of 13.
+    static const bool short_off = getenv("LLMIE_NO_FUSED_SHORT_PREFILL") != nullptr;
+    if (!short_off && !fp8 && T <= 128 && H % 256 == 0 && I % 256 == 0 && H >= 512 && I >= 512 && splitk_rownorm_eligible(H)) {
+        const SlabScale none{nullptr, nullptr, nullptr};
+        TIMED(LLMIE_OP_ATTN_NORM, llmie_rmsnorm(h, resid, dec->layers[0].attn_norm_gamma, c.rms_eps, T, H, LLMIE_F16, stream));
+        for (int l = 0; l < c.num_layers; ++l) {
+            const llmie_layer_weights &w = dec->layers[l];
+            const bool last = l + 1 == c.num_layers;
+            SplitKSlabs sk;
+            TIMED(LLMIE_OP_QKV_GEMM, linear_splitk_partial(16, h, w.qkv.data, T, H, QKV, st, &sk, nullptr));
+            TIMED(LLMIE_OP_QKV_GEMM, splitk_finalize(sk, none, qkv, EPI_NONE_, nullptr, nullptr, st));
+            TIMED(LLMIE_OP_MHA, prefill_attention_f16(qkv, (const half_t *)w.qkv.bias, k_cache, v_cache, attn, cum,
+                                                      history_lengths, dec->rope_table, l, batch, T, max_q_len, c.head_num,
+                                                      c.kv_head_num, c.head_size, c.max_seq_len, c.rotary_dim, st,
+                                                      c.kv_fmt == LLMIE_KV_FP8, c.k_scale > 0.f ? c.k_scale : 1.f,
+                                                      c.v_scale > 0.f ? c.v_scale : 1.f, dec->page_table, dec->max_pages, dec->num_pages));
+            TIMED(LLMIE_OP_O_GEMM, linear_splitk_partial(16, attn, w.o.data, T, H, H, st, &sk, nullptr));
+            // context_decoder.cpp: h += resid; resid = h; h += o.bias; h = rmsnorm(h, ffn_gamma)
+            TIMED(LLMIE_OP_FFN_NORM, splitk_rownorm(sk, none, static_cast<const half_t *>(w.o.bias), resid,
+                                                    static_cast<const half_t *>(w.ffn_norm_gamma), c.rms_eps, h, nullptr, nullptr, st));
+            TIMED(LLMIE_OP_GATE_UP_SWIGLU, linear_splitk_partial(16, h, w.gate_up.data, T, H, 2 * I, st, &sk, nullptr));
+            TIMED(LLMIE_OP_GATE_UP_SWIGLU, splitk_finalize(sk, none, act, EPI_SWIGLU_, nullptr, nullptr, st));
+            TIMED(LLMIE_OP_DOWN_GEMM, linear_splitk_partial(16, act, w.down.data, T, I, H, st, &sk, nullptr));
+            // h = act.Wd^T + resid, then the next layer's resid = h; h = rmsnorm(h) (last layer: h stays un-normalised)
+            const void *next_gamma = last ? nullptr : dec->layers[l + 1].attn_norm_gamma;
+            TIMED(LLMIE_OP_ATTN_NORM, splitk_rownorm(sk, none, nullptr, resid, static_cast<const half_t *>(next_gamma), c.rms_eps, h,
+                                                     nullptr, nullptr, st));
+        }
+        return LLMIE_OK;
+    }
     for (int l = 0; l < c.num_layers; ++l) {
         const llmie_layer_weights &w = dec->layers[l];
         TIMED(LLMIE_OP_ATTN_NORM, llmie_rmsnorm(h, resid, w.attn_norm_gamma, c.rms_eps, T, H, LLMIE_F16, stream));
