@@ -32,7 +32,7 @@ template <bool FP8, bool HAS_EPI, int WN = 4, bool SWIGLU = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(const void *__restrict__ Xv, const void *__restrict__ Wv, half_t *C,
                                                       int M, int N, int K, const half_t *__restrict__ bias,
                                                       const half_t *residual, int tiles_n, const float *__restrict__ xscale,
-                                                      const float *__restrict__ wscale, int ldc_arg = 0) {
+                                                      const float *__restrict__ wscale, int ldc_arg = 0, int group_m = 0) {
     // ldc_arg != 0: C (and residual) rows are ldc_arg elements apart -- a launch over a column range [n_begin, n_begin + N)
     // of a wider output, with W / bias / wscale / C / residual pointers already advanced to n_begin
     const size_t ldc = ldc_arg ? ldc_arg : N;
@@ -50,7 +50,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const void *__restrict__ X
     const int r = lane & 15, q = lane >> 4;
     // consecutive workgroups walk down M inside one 256-wide column of W: the W tile is shared through L2 by the
     // workgroups that are resident together, X (the smaller operand at prefill) is re-read per column
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    int tile_m, tile_n;
+    if (group_m > 0) {
+        // XCD-aware tile order.  The dispatcher hands workgroup id i to XCD i % 8 and each XCD has its own L2: give every XCD a
+        // CONTIGUOUS range of logical tiles, and walk that range in groups of group_m row tiles x all column tiles, M fastest --
+        // the ~32 workgroups an XCD runs together then cover a compact block (group_m X tiles x 8 W tiles) whose operands
+        // they share through that L2 instead of 32 unrelated tiles.
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int qd = nwg >> 3, rem = nwg & 7;
+        const int L = xcd * qd + min(xcd, rem) + idx;  // XCD x owns qd + (x < rem) consecutive logical ids
+        const int tm = (M + 255) / 256, per_group = group_m * tiles_n;
+        const int grp = L / per_group, in = L - grp * per_group;
+        const int first_m = grp * group_m, gsz = min(tm - first_m, group_m);
+        tile_m = first_m + in % gsz;
+        tile_n = in / gsz;
+    } else {
+        tile_m = blockIdx.x / tiles_n;
+        tile_n = blockIdx.x - tile_m * tiles_n;
+    }
     const int m0 = tile_m * 256, n0 = tile_n * BN;
 
     // ---- LDS-DMA plan: half-tile h (0,1 = X rows m0 + 128 h ..; 2,3 = W rows n0 + 128 (h-2) ..), instruction i (0,1):

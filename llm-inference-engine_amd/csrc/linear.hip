@@ -477,6 +477,10 @@ int linear_f16_nk_norm(const half_t *x, const half_t *W, half_t *y, int M, int K
 
 // 256 x 256 (or 256 x 128) LDS-DMA GEMM (gemm256.cuh): fp16 operands, or e4m3 operands with per-token / per-row scales.
 // Tile choice by grid fill: 256-wide column tiles when they give >= min_tiles workgroups (one per CU), else 128-wide.
+static int g256_group_m() {
+    static const int v = env_int("LLMIE_GEMM256_GROUP_M", 4);
+    return v;
+}
 static int gemm256_wn(int M, int N) {
     static const int min_tiles = env_int("LLMIE_GEMM256_MIN_TILES", 192);
     const int tm = (M + 255) / 256;
@@ -497,7 +501,7 @@ static void gemm256_launch_t(const void *x, const void *W, half_t *y, int M, int
         attr_set = true;
     }
     const int tm = (M + 255) / 256, tn = (N + 64 * WN - 1) / (64 * WN);
-    gemm256_kernel<FP8, EPI, WN><<<tm * tn, 512, lds_bytes, st>>>(x, W, y, M, N, K, bias, residual, tn, xscale, wscale, ldc);
+    gemm256_kernel<FP8, EPI, WN><<<tm * tn, 512, lds_bytes, st>>>(x, W, y, M, N, K, bias, residual, tn, xscale, wscale, ldc, g256_group_m());
 }
 
 // SwiGLU form: W = fused gate_up [2I, K], y = silu(x.Wg^T) * (x.Wu^T) [M, I]
@@ -519,9 +523,9 @@ void gemm256_swiglu_launch(bool fp8, const void *x, const void *W, half_t *y, in
     }
     const int tm = (M + 255) / 256, tn = (two_inter / 2 + 127) / 128;
     if (fp8)
-        gemm256_kernel<true, false, 4, true><<<tm * tn, 512, lds_bytes, st>>>(x, W, y, M, two_inter, K, nullptr, nullptr, tn, xscale, wscale);
+        gemm256_kernel<true, false, 4, true><<<tm * tn, 512, lds_bytes, st>>>(x, W, y, M, two_inter, K, nullptr, nullptr, tn, xscale, wscale, 0, g256_group_m());
     else
-        gemm256_kernel<false, false, 4, true><<<tm * tn, 512, lds_bytes, st>>>(x, W, y, M, two_inter, K, nullptr, nullptr, tn, nullptr, nullptr);
+        gemm256_kernel<false, false, 4, true><<<tm * tn, 512, lds_bytes, st>>>(x, W, y, M, two_inter, K, nullptr, nullptr, tn, nullptr, nullptr, 0, g256_group_m());
 }
 
 // One launch over the column range [nb, nb + n) of the [M, N] output with 64*wn-column tiles.
