@@ -246,29 +246,43 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
         for (int s = 0; s < 4; ++s)  // 4 independent accumulators per k-step: no back-to-back dependent MFMAs
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) sacc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[tt][s], qf[s], sacc[tt], 0, 0, 0);
-        // lane holds S[qrow][t = t0 + 16 tt + 4 q + e]; mask + scale
+        // lane holds S[qrow][t = t0 + 16 tt + 4 q + e].  Softmax in the log2 domain: s2 = S * scale * log2(e), p = 2^(s2 - m)
+        // (one v_exp_f32 per element, no separate multiply); the causal / length mask is only evaluated on tiles that reach past
+        // the wave's first query position or the context end (wave-uniform test), and 2^(-inf) = 0 needs no select.
+        const float scale2 = scale * 1.44269504088896341f;
+        const bool need_mask = t0 + BT - 1 > history + q0 + wave * 16 || t0 + BT > ctx;
         float mloc = -INFINITY;
+        if (need_mask) {
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
+            for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int t = t0 + tt * 16 + 4 * q + e;
-                const float v = (t <= qpos && t < ctx) ? sacc[tt][e] * scale : -INFINITY;
-                sacc[tt][e] = v;
-                mloc = fmaxf(mloc, v);
-            }
+                for (int e = 0; e < 4; ++e) {
+                    const int t = t0 + tt * 16 + 4 * q + e;
+                    const float v = (t <= qpos && t < ctx) ? sacc[tt][e] * scale2 : -INFINITY;
+                    sacc[tt][e] = v;
+                    mloc = fmaxf(mloc, v);
+                }
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sacc[tt][e] *= scale2;
+                    mloc = fmaxf(mloc, sacc[tt][e]);
+                }
+        }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float m_new = fmaxf(m_run, mloc);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: keep everything at zero
-        const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_use);
+        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_use);
         float lsum = 0.f;
         half8_t pf[2];  // P^T fragments = MFMA B operand of the two 32-key steps
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float p = (sacc[tt][e] == -INFINITY) ? 0.f : __expf(sacc[tt][e] - m_use);
+                const float p = __builtin_amdgcn_exp2f(sacc[tt][e] - m_use);
                 lsum += p;
                 pf[tt >> 1][(tt & 1) * 4 + e] = from_f32<half_t>(p);
             }
@@ -276,8 +290,11 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
         lsum += __shfl_xor(lsum, 32, 64);
         l_run = l_run * alpha + lsum;
         m_run = m_new;
+        // the running maximum rarely moves after the first tiles: skip the 32 rescaling multiplies when no row of the wave needs them
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) o[dt] *= alpha;
+            for (int dt = 0; dt < 8; ++dt) o[dt] *= alpha;
+        }
         // ---- O^T += V^T . P^T : A fragment = V[t(q,j)][d = 16 dt + r] gathered down a column ----
         // lane (r, q) of its 16-lane group supplies the address of block row (r >> 2), columns 4 (r & 3) .. +3, and receives
         // column r of the block's 4 rows; all 16 transposed reads of a 32-key step are issued before its 8 MFMAs
