@@ -35,8 +35,49 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const half_t *__
     }
 }
 
+// Same arithmetic with the row held in registers: 16-byte loads (R chunks of 8 halves per thread), one pass over memory
+// (read 2K + write K bytes per row) -- the scalar two-pass form above ran at 1.2 TB/s on [4096, 11008] activations.
+template <int R>
+__global__ __launch_bounds__(256) void quantize_rows_fp8_vec_kernel(const half_t *__restrict__ w, uint8_t *__restrict__ q,
+                                                                    float *__restrict__ scale, int K) {
+    __shared__ float red[4];
+    const size_t row = blockIdx.x;
+    const half8_t *src = reinterpret_cast<const half8_t *>(w + row * K);
+    const int nch = K / 8;
+    half8_t v[R];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        v[i] = src[c < nch ? c : nch - 1];
+        if (c < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(to_f32(v[i][e])));
+        }
+    }
+    amax = block_max<4>(amax, red);
+    const float s = amax > 0.f ? amax / 448.0f : 1.0f;
+    if (threadIdx.x == 0) scale[row] = s;
+    uint2 *dst = reinterpret_cast<uint2 *>(q + row * K);
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < nch)
+            dst[c] = uint2{pack4_e4m3(to_f32(v[i][0]) / s, to_f32(v[i][1]) / s, to_f32(v[i][2]) / s, to_f32(v[i][3]) / s),
+                           pack4_e4m3(to_f32(v[i][4]) / s, to_f32(v[i][5]) / s, to_f32(v[i][6]) / s, to_f32(v[i][7]) / s)};
+    }
+}
+
 int quantize_rows_fp8(const half_t *x, uint8_t *xq, float *xscale, int M, int K, hipStream_t st) {
-    quantize_rows_fp8_kernel<float><<<M, 256, 0, st>>>(x, xq, xscale, K);
+    const int per_thread = (K / 8 + 255) / 256;
+    if (K % 8 == 0 && per_thread <= 8 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(xq) % 8 == 0) {
+        if (per_thread <= 2) quantize_rows_fp8_vec_kernel<2><<<M, 256, 0, st>>>(x, xq, xscale, K);
+        else if (per_thread <= 4) quantize_rows_fp8_vec_kernel<4><<<M, 256, 0, st>>>(x, xq, xscale, K);
+        else if (per_thread <= 6) quantize_rows_fp8_vec_kernel<6><<<M, 256, 0, st>>>(x, xq, xscale, K);
+        else quantize_rows_fp8_vec_kernel<8><<<M, 256, 0, st>>>(x, xq, xscale, K);
+    } else {
+        quantize_rows_fp8_kernel<float><<<M, 256, 0, st>>>(x, xq, xscale, K);
+    }
     return launch_status("quantize_rows_fp8");
 }
 
@@ -70,8 +111,7 @@ extern "C" size_t llmie_linear_fp8_workspace_bytes(int M, int K) {
 
 extern "C" int llmie_quantize_fp8(const void *w, uint8_t *wq, float *scale, int N, int K, llmie_stream stream) {
     LLMIE_REQUIRE(w && wq && scale && N > 0 && K > 0 && K % 4 == 0, "quantize_fp8: bad arguments (K %% 4 == 0)");
-    quantize_rows_fp8_kernel<float><<<N, 256, 0, as_stream(stream)>>>((const half_t *)w, wq, scale, K);
-    return launch_status("quantize_fp8");
+    return quantize_rows_fp8((const half_t *)w, wq, scale, N, K, as_stream(stream));
 }
 
 extern "C" int llmie_linear_fp8(const void *x, const uint8_t *w_fp8, const float *w_scale, void *y, int M, int K, int N,
