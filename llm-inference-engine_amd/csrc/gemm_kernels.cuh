@@ -9,6 +9,9 @@
 //                          waves split K, v_mfma_f32_16x16x32_f16 with W as the A operand (so the
 //                          weight fragment is one 16-byte load per lane) and x^T as B, LDS reduce
 //                          across the K-split.  HBM-bound.
+//   skinny_splitk_kernel   8 < M <= 64 per pass (fp16 / int8 / int4 / fp8): 64 weight rows x one K slice per workgroup,
+//                          fp32 slabs [KS][M][N] reduced by their consumer.  (64 < M <= 128: gemm_mid.cuh;
+//                          prefill-sized M: gemm256.cuh.)
 //   tiled_mfma_f16_kernel  M > 64 (prefill): 128x128x32 LDS-tiled MFMA GEMM.  MFMA-bound.
 //   generic_gemm_kernel    any dtype/transposition/shape: 64x64x16 LDS-tiled fp32 FMA.
 //
