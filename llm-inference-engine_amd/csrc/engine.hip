@@ -608,16 +608,39 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
         }
         return LLMIE_OK;
     }
+    // fp8, prefill-sized: the two RMSNorms emit the e4m3 activations of the projection behind them (norm.hip
+    // rmsnorm_quant_kernel; bit-identical to norm + quantize_rows) and the tiled fp8 GEMM takes them as they are
+    const bool nq = fp8 && T > 8 && H % 128 == 0 && rmsnorm_quant_eligible(H);
+    uint8_t *xqn = static_cast<uint8_t *>(f8ws);
+    float *xsn = reinterpret_cast<float *>(xqn + ((static_cast<size_t>(T) * H + 255) & ~static_cast<size_t>(255)));
+    auto tiled_fp8 = [&](const llmie_matrix &w, int N) {
+        return nq && gemm256_fills(T, N) && N % 4 == 0 && (reinterpret_cast<uintptr_t>(w.data) | reinterpret_cast<uintptr_t>(w.scale)) % 16 == 0;
+    };
     for (int l = 0; l < c.num_layers; ++l) {
         const llmie_layer_weights &w = dec->layers[l];
+        if (tiled_fp8(w.qkv, QKV)) {
+            TIMED(LLMIE_OP_ATTN_NORM, rmsnorm_quant_f16(h, resid, nullptr, (const half_t *)w.attn_norm_gamma, c.rms_eps, T, H, false, xqn, xsn, st));
+            TIMED(LLMIE_OP_QKV_GEMM, (gemm256_launch(true, xqn, w.qkv.data, qkv, T, QKV, H, nullptr, nullptr, xsn, (const float *)w.qkv.scale, st),
+                                      launch_status("decoder_prefill(qkv fp8)")));
+        } else {
         TIMED(LLMIE_OP_ATTN_NORM, llmie_rmsnorm(h, resid, w.attn_norm_gamma, c.rms_eps, T, H, LLMIE_F16, stream));
         TIMED(LLMIE_OP_QKV_GEMM, proj(h, w.qkv, qkv, H, QKV, nullptr));
+        }
         TIMED(LLMIE_OP_MHA, prefill_attention_f16(qkv, (const half_t *)w.qkv.bias, k_cache, v_cache, attn, cum,
                                                   history_lengths, dec->rope_table, l, batch, T, max_q_len, c.head_num,
                                                   c.kv_head_num, c.head_size, c.max_seq_len, c.rotary_dim, st,
                                                   c.kv_fmt == LLMIE_KV_FP8, c.k_scale > 0.f ? c.k_scale : 1.f,
                                                   c.v_scale > 0.f ? c.v_scale : 1.f, dec->page_table, dec->max_pages, dec->num_pages));
         TIMED(LLMIE_OP_O_GEMM, proj(attn, w.o, h, H, H, nullptr));
+        const bool gu_fused8 = fp8 && gemm256_swiglu_fills(T, 2 * I) && H % 128 == 0 && reinterpret_cast<uintptr_t>(w.gate_up.data) % 16 == 0;
+        if (nq && gu_fused8 && w.ffn_norm_gamma && reinterpret_cast<uintptr_t>(w.gate_up.scale) % 16 == 0) {
+            TIMED(LLMIE_OP_FFN_NORM, rmsnorm_quant_f16(h, resid, (const half_t *)w.o.bias, (const half_t *)w.ffn_norm_gamma, c.rms_eps, T, H, true,
+                                                       xqn, xsn, st));
+            TIMED(LLMIE_OP_GATE_UP_SWIGLU, (gemm256_swiglu_launch(true, xqn, w.gate_up.data, act, T, 2 * I, H, xsn, (const float *)w.gate_up.scale, st),
+                                            launch_status("decoder_prefill(gate_up fp8)")));
+            TIMED(LLMIE_OP_DOWN_GEMM, proj(act, w.down, h, I, H, resid));
+            continue;
+        }
         TIMED(LLMIE_OP_FFN_NORM, llmie_fused_add_bias_residual_rmsnorm(resid, h, w.o.bias, w.ffn_norm_gamma, c.rms_eps, T, H,
                                                                        LLMIE_F16, stream));
         // ffn.cpp:105-122: act = silu(h.Wg^T) * (h.Wu^T); SwiGLU fused into the projection's epilogue where a fused form exists

@@ -8,6 +8,9 @@
 // variants are defective and are NOT reproduced: fp16 uses the same
 // math with fp32 accumulation and one rounding per stored element.
 #include "device_utils.cuh"
+#include "llmie_internal.h"
+
+#include <cstdlib>
 
 namespace llmie {
 
@@ -73,6 +76,96 @@ __global__ __launch_bounds__(BLOCK) void rmsnorm_kernel(
             }
         }
     }
+}
+
+// fp8 engines, prefill: the RMSNorm in front of a projection emits that projection's per-token e4m3 activations directly
+// (scale = amax/448 of the fp16-rounded normalised row: bit-identical to rmsnorm_kernel followed by quantize_rows_fp8) -- the
+// normalised fp16 row, which nothing else reads, is never written, and the quantisation launch disappears.
+template <bool FUSED>
+__global__ __launch_bounds__(256) void rmsnorm_quant_kernel(const half_t *__restrict__ x, half_t *__restrict__ resid,
+                                                            const half_t *__restrict__ bias, const half_t *__restrict__ gamma,
+                                                            float eps, int hidden, uint8_t *__restrict__ xq, float *__restrict__ xscale) {
+    constexpr int MAXV = 4;
+    __shared__ float red[4];
+    const int nvec = hidden / 8;
+    const size_t row = static_cast<size_t>(blockIdx.x) * hidden;
+    const half8_t *xv = reinterpret_cast<const half8_t *>(x + row);
+    half8_t *rv = resid ? reinterpret_cast<half8_t *>(resid + row) : nullptr;
+    const half8_t *bv = reinterpret_cast<const half8_t *>(bias);
+    const half8_t *gv = reinterpret_cast<const half8_t *>(gamma);
+    half8_t keep[MAXV];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int i = threadIdx.x + j * 256;
+        if (i < nvec) {
+            half8_t v = xv[i];
+            if constexpr (FUSED) {
+                if (rv) {
+                    const half8_t r = rv[i];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = from_f32<half_t>(to_f32(v[e]) + to_f32(r[e]));
+                    rv[i] = v;
+                }
+                if (bv) {
+                    const half8_t b = bv[i];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = from_f32<half_t>(to_f32(v[e]) + to_f32(b[e]));
+                }
+            } else {
+                if (rv) rv[i] = v;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += to_f32(v[e]) * to_f32(v[e]);
+            keep[j] = v;
+        }
+    }
+    ss = block_sum<4>(ss, red);
+    const float inv = rsqrtf(ss / static_cast<float>(hidden) + eps);
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int i = threadIdx.x + j * 256;
+        if (i < nvec) {
+            const half8_t g = gv[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                keep[j][e] = from_f32<half_t>(to_f32(keep[j][e]) * to_f32(g[e]) * inv);
+                amax = fmaxf(amax, fabsf(to_f32(keep[j][e])));
+            }
+        }
+    }
+    amax = block_max<4>(amax, red);
+    const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+    if (threadIdx.x == 0) xscale[blockIdx.x] = sc;
+    uint2 *dst = reinterpret_cast<uint2 *>(xq + row);
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int i = threadIdx.x + j * 256;
+        if (i < nvec) {
+            const half8_t v = keep[j];
+            dst[i] = uint2{pack4_e4m3(to_f32(v[0]) / sc, to_f32(v[1]) / sc, to_f32(v[2]) / sc, to_f32(v[3]) / sc),
+                           pack4_e4m3(to_f32(v[4]) / sc, to_f32(v[5]) / sc, to_f32(v[6]) / sc, to_f32(v[7]) / sc)};
+        }
+    }
+}
+
+bool rmsnorm_quant_eligible(int hidden) {
+    static const bool off = getenv("LLMIE_NO_NORM_QUANT") != nullptr;
+    return !off && hidden % 8 == 0 && hidden / 8 <= 1024;
+}
+// fused == false: resid = x (copy, nullable); fused == true: x += resid; resid = x; x += bias -- then e4m3(norm(x) * gamma)
+int rmsnorm_quant_f16(const half_t *x, half_t *resid, const half_t *bias, const half_t *gamma, float eps, int tokens, int hidden,
+                      bool fused, uint8_t *xq, float *xscale, hipStream_t st) {
+    if (!gamma || !xq || !xscale || hidden % 8 || hidden / 8 > 1024 ||
+        (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(resid) | reinterpret_cast<uintptr_t>(bias) |
+         reinterpret_cast<uintptr_t>(gamma)) % 16 || reinterpret_cast<uintptr_t>(xq) % 8) {
+        set_error("rmsnorm_quant: unsupported shape / alignment (hidden %d)", hidden);
+        return LLMIE_ERR_UNSUPPORTED;
+    }
+    if (fused) rmsnorm_quant_kernel<true><<<tokens, 256, 0, st>>>(x, resid, bias, gamma, eps, hidden, xq, xscale);
+    else rmsnorm_quant_kernel<false><<<tokens, 256, 0, st>>>(x, resid, nullptr, gamma, eps, hidden, xq, xscale);
+    return launch_status("rmsnorm_quant");
 }
 
 // Any hidden size (unaligned / huge rows): scalar, two passes (second pass hits L2).

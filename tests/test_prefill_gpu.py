@@ -155,3 +155,56 @@ def test_fp8_prefill_consistent_with_fp8_decode_and_tracks_fp16(llmie):
     assert rel16 < 0.12, rel16  # measured 0.079: two layers x (e4m3 weights + e4m3 activations), 3 mantissa bits each
     d8.close()
     d16.close()
+
+
+_NORM_QUANT_SCRIPT = r"""
+import sys, os, importlib.util, numpy as np, torch
+root = sys.argv[1]
+spec = importlib.util.spec_from_file_location("llmie_amd", os.path.join(root, "llm-inference-engine_amd", "__init__.py"))
+llmie = importlib.util.module_from_spec(spec); sys.modules["llmie_amd"] = llmie; spec.loader.exec_module(llmie)
+torch.manual_seed(11)
+nh, hs, I, L, max_seq, T = 32, 128, 11008, 2, 1024, 1024
+H, QKV = nh * hs, 3 * nh * hs
+layers = []
+for l in range(L):
+    m = {}
+    for k, (n, kk) in dict(qkv=(QKV, H), o=(H, H), gate_up=(2 * I, H), down=(H, I)).items():
+        w = ((torch.rand((n, kk), device="cuda") * 2 - 1) * 2 / kk ** 0.5).half()
+        q = torch.empty((n, kk), dtype=torch.uint8, device="cuda"); s = torch.empty(n, dtype=torch.float32, device="cuda")
+        llmie.quantize_fp8(w, q, s)
+        m[k] = dict(data=q, scale=s)
+        del w
+    g1 = (torch.rand(H, device="cuda") * 0.4 + 0.8).half()
+    g2 = (torch.rand(H, device="cuda") * 0.4 + 0.8).half()
+    layers.append(dict(attn_norm=g1, ffn_norm=g2, **m))
+cfg = dict(head_num=nh, kv_head_num=nh, head_size=hs, inter_size=I, num_layers=L, vocab_size=100, max_seq_len=max_seq,
+           max_batch=2, rotary_dim=hs, rotary_base=10000.0, rms_eps=1e-5, dtype=llmie.F16, int4_group=128, wfmt=llmie.W_FP8)
+dec = llmie.Decoder(cfg, layers)
+x = torch.randn((T, H), device="cuda").half()
+kc = torch.zeros((L, 2, nh, max_seq, hs), device="cuda", dtype=torch.float16)
+vc = torch.zeros_like(kc)
+i32 = lambda v: torch.tensor(v, dtype=torch.int32, device="cuda")
+out = dec.prefill(x, torch.empty_like(x), kc, vc, i32([600, 424]), i32([0, 0]), 600)
+np.save(sys.argv[2], np.concatenate([out.float().cpu().numpy().ravel(), kc[1, 1, 3, :424].float().cpu().numpy().ravel()]))
+"""
+
+
+def test_fp8_prefill_norm_quant_fusion_is_bit_identical(tmp_path):
+    """fp8 prefill: RMSNorm kernels that emit the per-token e4m3 activations directly (rmsnorm_quant_kernel + pre-quantised
+    tiled GEMM) against RMSNorm -> quantize_rows -> GEMM (LLMIE_NO_NORM_QUANT=1): hidden states and cache rows bit-equal.
+    One process per setting (the switch is read once per process)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "run.py"
+    script.write_text(_NORM_QUANT_SCRIPT)
+    outs = []
+    for flag in (None, "1"):
+        env = dict(os.environ)
+        env.pop("LLMIE_NO_NORM_QUANT", None)
+        if flag:
+            env["LLMIE_NO_NORM_QUANT"] = flag
+        dst = tmp_path / ("out_%s.npy" % (flag or "fused"))
+        subprocess.run([sys.executable, str(script), root, str(dst)], check=True, env=env, timeout=600)
+        outs.append(np.load(dst))
+    assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
+    assert np.array_equal(outs[0], outs[1])
