@@ -147,8 +147,8 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
     float *__restrict__ part, T *__restrict__ out, int head_num, int kv_head_num, int max_seq_len,
     int step_arg, const int32_t *__restrict__ step_dev, int max_splits,
     const float2 *__restrict__ rope /* [max_pos][HS/2] (cos,sin) or null */, int rotary_dim,
-    int32_t *tickets_arg /* [batch, kv_head_num] zero-initialised arrival counters, or null = separate merge kernel; bit 0 set
-                            = experimental write-through hand-off (no release / acquire fences) */,
+    int32_t *tickets /* [batch, kv_head_num] zero-initialised arrival counters, or null = separate merge kernel */,
+    const int wt_merge /* in-launch merge only: 1 = experimental write-through hand-off (no release / acquire fences) */,
     const QkvSlabs qs /* qs.slab != null: q/k/v come from the split-K partial slabs of the QKV projection (qkv unused) */,
     const float k_scale, const float v_scale /* fp8 cache: stored = e4m3(x / scale); 1 otherwise */,
     const PagedKv pg /* pg.table != null: k_cache / v_cache are this layer's page pools */) {
@@ -158,8 +158,6 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
     constexpr int NT = kAttnWaves * 64;
     static_assert(HS % N == 0 && LPT >= 1 && LPT <= 64 && (LPT & (LPT - 1)) == 0, "head size");
 
-    const bool wt_merge = reinterpret_cast<uintptr_t>(tickets_arg) & 1;
-    int32_t *tickets = reinterpret_cast<int32_t *>(reinterpret_cast<uintptr_t>(tickets_arg) & ~static_cast<uintptr_t>(1));
     const int step = step_dev ? *step_dev : step_arg;
     const int split = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
     const int t0 = split * CHUNK;
@@ -614,7 +612,6 @@ static void launch_split(const T *qkv, const T *bias, KT *kc, KT *vc, float *par
                          KvScale ks, PagedKv pg, hipStream_t st) {
     static const int cfg = getenv("LLMIE_ATTN_CFG") ? atoi(getenv("LLMIE_ATTN_CFG")) : 0;
     static const bool wt = getenv("LLMIE_ATTN_MERGE_IN_KERNEL") && atoi(getenv("LLMIE_ATTN_MERGE_IN_KERNEL")) == 2;
-    if (wt && tickets) tickets = reinterpret_cast<int32_t *>(reinterpret_cast<uintptr_t>(tickets) | 1);
     const int bound = step_dev ? max_seq_len : step;
     int CHUNK, splits;
 #define LLMIE_ATTN_LAUNCH(NWV_, GL_)                                                                                   \
@@ -624,7 +621,7 @@ static void launch_split(const T *qkv, const T *bias, KT *kc, KT *vc, float *par
         dim3 grid(splits, kv_head_num, batch);                                                                          \
         decode_attn_split_kernel<T, HS, REP, NWV_, GL_, KT><<<grid, NWV_ * 64, 0, st>>>(                                \
             qkv, bias, kc, vc, part, out, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, \
-            tickets, qs, ks.k, ks.v, pg);                                                                               \
+            tickets, wt ? 1 : 0, qs, ks.k, ks.v, pg);                                                                   \
     } while (0)
     if (cfg == 1) LLMIE_ATTN_LAUNCH(8, 8);
     else if (cfg == 2) LLMIE_ATTN_LAUNCH(4, 4);
