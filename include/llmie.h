@@ -209,7 +209,8 @@ int llmie_linear_w4a16(const void *x, const uint8_t *wq, const void *scale, void
                        llmie_stream stream);
 /* fp8 e4m3 (OCP) weights [N,K] with per-row fp32 scale; x fp16 is quantised per token to e4m3
  * on the fly (scale = amax/448); y[m,n] = w_scale[n] * x_scale[m] * sum_k wq[n,k] xq[m,k], fp32 accumulate; y fp16.
- * M <= 8: K-split GEMV (same arithmetic on the VALU); 8 < M: split-K fp8 MFMA (K % 256 == 0, K >= 512);
+ * M <= 8: K-split GEMV (same arithmetic on the VALU); 8 < M: split-K fp8 MFMA (K % 256 == 0, K >= 512; 64 < M <= 128 rows per
+ * pass take the 128-row LDS-DMA form);
  * prefill-sized M x N (>= 192 tiles of 256 x 256 or 256 x 128): tiled v_mfma_scale_f32_16x16x128_f8f6f4 GEMM
  * (K % 128 == 0).  workspace = quantised activations + per-token scales. */
 int llmie_linear_fp8(const void *x, const uint8_t *w_fp8, const float *w_scale, void *y,
