@@ -286,8 +286,8 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
                 lsum += p;
                 pf[tt >> 1][(tt & 1) * 4 + e] = from_f32<half_t>(p);
             }
-        lsum += __shfl_xor(lsum, 16, 64);
-        lsum += __shfl_xor(lsum, 32, 64);
+        // l_run is this lane's PARTIAL row sum (its 16 of the tile's 64 keys): alpha is the same for the 4 lanes of a row, so the
+        // cross-lane reduction is linear and done once after the last tile instead of two LDS-path shuffles per tile
         l_run = l_run * alpha + lsum;
         m_run = m_new;
         // the running maximum rarely moves after the first tiles: skip the 32 rescaling multiplies when no row of the wave needs them
@@ -318,6 +318,8 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
             }
         }
     }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
     if (qrow < len) {
         const float inv = 1.0f / (l_run + 1e-6f);  // the reference's denominator epsilon (scale_and_mask_and_softmax.cu:118)
         half_t *optr = out + (static_cast<size_t>(cum[b] + qrow) * head_num + h) * HS;
