@@ -1,4 +1,5 @@
-// Split-K MFMA GEMM for 64 < M <= 128 activation rows (decode batches of 65..128 sequences, 128-token prefills):
+// Split-K MFMA GEMM for 32 < M <= 128 activation rows (decode batches of 33..128 sequences, short prefills; XR = 64 or 128
+// staged activation rows):
 //   slab[ks][m][n] = sum_{k in slice ks} X[m,k] * W[n,k]        (fp32 partials, consumed like skinny_splitk_kernel's)
 // -- the linear of launchLinearGemm (linear.cu:10-87) where the weight stream still bounds the op (128 flop per weight
 // byte) but the 64-row skinny kernel re-stages the 128-row activation tile through VGPRs once per 64 weight rows (L2
@@ -18,14 +19,19 @@ namespace llmie {
 
 typedef int mid_intx8 __attribute__((ext_vector_type(8)));
 
-template <bool FP8, int WN, int NS>
+template <bool FP8, int WN, int NS, int XR = 128>
 __global__ __launch_bounds__(512) void mid_splitk_kernel(const void *__restrict__ Xv, const void *__restrict__ Wv,
                                                          float *__restrict__ slab, int M, int N, int K, int KS, int kt_per_slice) {
     constexpr int ES = FP8 ? 1 : 2;   // bytes per element
     constexpr int BK = 128 / ES;      // k per tile: rows of 128 bytes either way
-    constexpr int NHALF = 1 + WN / 2; // 128-row halves per stage: X, W0, [W1]
-    constexpr int HALF_BYTES = 128 * 128, STAGE_BYTES = NHALF * HALF_BYTES;
-    constexpr int IPT = 2 * NHALF;    // LDS-DMA instructions per wave per k-tile
+    // XR = activation rows staged per k-tile: 128, or 64 for M <= 64 (half the X tile: a 4th stage fits the 160 KiB and
+    // three k-tiles of weights stay in flight per CU)
+    constexpr int NHALF = 1 + WN / 2; // halves per stage: X (XR rows), W0, [W1] (128 rows each)
+    constexpr int HALF_BYTES = 128 * 128, X_BYTES = XR * 128, STAGE_BYTES = X_BYTES + (WN / 2) * HALF_BYTES;
+    constexpr int X_INSTR = XR / 64;  // LDS-DMA instructions per wave for the X tile (8 rows each)
+    constexpr int IPT = X_INSTR + WN; // LDS-DMA instructions per wave per k-tile
+    constexpr int MI = XR / 32;       // 16-row activation tiles per wave (wave grid 2 x 4)
+    static_assert(XR == 128 || XR == 64, "activation rows per stage");
     static_assert(WN == 2 || WN == 4, "128 or 256 weight rows per workgroup");
     static_assert(NS >= 2 && (NS - 2) * IPT < 64, "vmcnt is a 6-bit counter");
     const unsigned char *X = static_cast<const unsigned char *>(Xv), *W = static_cast<const unsigned char *>(Wv);
@@ -46,7 +52,7 @@ __global__ __launch_bounds__(512) void mid_splitk_kernel(const void *__restrict_
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = (i * 8 + wave) * 8 + (lane >> 3), slot = lane & 7, chunk = slot ^ (row & 7);
-            const int grow = h == 0 ? min(row, M - 1) : min(n0 + (h - 1) * 128 + row, N - 1);  // clamped rows are never stored
+            const int grow = h == 0 ? min(min(row, XR - 1), M - 1) : min(n0 + (h - 1) * 128 + row, N - 1);  // clamped rows are never stored
             src[h][i] = (h == 0 ? X : W) + (static_cast<size_t>(grow) * K + static_cast<size_t>(kt0) * BK) * ES + chunk * 16;
         }
     // Workgroups of one K slice run in lock step and a k-tile of 128-byte row pieces at an 8 KiB row pitch lands in ONE L2
@@ -58,23 +64,23 @@ __global__ __launch_bounds__(512) void mid_splitk_kernel(const void *__restrict_
 #pragma unroll
         for (int h = 0; h < NHALF; ++h)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                unsigned char *dst = lds + stage * STAGE_BYTES + h * HALF_BYTES + (i * 8 + wave) * 1024;  // wave-uniform
+            for (int i = 0; i < (h == 0 ? X_INSTR : 2); ++i) {
+                unsigned char *dst = lds + stage * STAGE_BYTES + (h == 0 ? 0 : X_BYTES + (h - 1) * HALF_BYTES) + (i * 8 + wave) * 1024;  // wave-uniform
                 typedef const __attribute__((address_space(1))) void *gptr_t;
                 typedef __attribute__((address_space(3))) void *lptr_t;
                 __builtin_amdgcn_global_load_lds((gptr_t)(src[h][i] + static_cast<size_t>(t) * 128), (lptr_t)dst, 16, 0, 0);
             }
     };
 
-    floatx4 acc[4][WN];
+    floatx4 acc[MI][WN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     const int wcol = wc * 16 * WN;  // first weight row of this wave inside the workgroup tile
-    const int a_row0 = wr * 64 + r, b_row0 = (wcol & 127) + r;
-    const unsigned char *a_base = lds, *b_base = lds + (1 + (wcol >> 7)) * HALF_BYTES;
+    const int a_row0 = wr * (XR / 2) + r, b_row0 = (wcol & 127) + r;
+    const unsigned char *a_base = lds, *b_base = lds + X_BYTES + (wcol >> 7) * HALF_BYTES;
     auto frag = [&](const unsigned char *base, int row, int c) {
         return *reinterpret_cast<const half8_t *>(base + row * 128 + ((c ^ (row & 7)) << 4));
     };
@@ -96,13 +102,13 @@ __global__ __launch_bounds__(512) void mid_splitk_kernel(const void *__restrict_
         if (kt + NS - 1 < nk) dma_tile(kt + NS - 1, fill);
         const unsigned char *ab = a_base + stage * STAGE_BYTES, *bb = b_base + stage * STAGE_BYTES;
         if constexpr (FP8) {
-            mid_intx8 bf[WN], af[4];
+            mid_intx8 bf[WN], af[MI];
 #pragma unroll
             for (int j = 0; j < WN; ++j) bf[j] = frag8(bb, b_row0 + j * 16);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = frag8(ab, a_row0 + i * 16);
+            for (int i = 0; i < MI; ++i) af[i] = frag8(ab, a_row0 + i * 16);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[j], af[i], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0,
@@ -110,14 +116,14 @@ __global__ __launch_bounds__(512) void mid_splitk_kernel(const void *__restrict_
         } else {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                half8_t bf[WN], af[4];
+                half8_t bf[WN], af[MI];
 #pragma unroll
                 for (int j = 0; j < WN; ++j) bf[j] = frag(bb, b_row0 + j * 16, s * 4 + q);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) af[i] = frag(ab, a_row0 + i * 16, s * 4 + q);
+                for (int i = 0; i < MI; ++i) af[i] = frag(ab, a_row0 + i * 16, s * 4 + q);
                 // D[n-row, m-col]: W as the MFMA A operand -> 4 consecutive n per lane (16-byte fp32 stores)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
             }
@@ -125,10 +131,10 @@ __global__ __launch_bounds__(512) void mid_splitk_kernel(const void *__restrict_
         stage = stage + 1 == NS ? 0 : stage + 1;
         fill = fill + 1 == NS ? 0 : fill + 1;
     }
-    // acc[i][j]: lane holds rows m = wr*64 + i*16 + r, columns n0 + wcol + j*16 + 4q + e
+    // acc[i][j]: lane holds rows m = wr*(XR/2) + i*16 + r, columns n0 + wcol + j*16 + 4q + e
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = wr * 64 + i * 16 + r;
+    for (int i = 0; i < MI; ++i) {
+        const int m = wr * (XR / 2) + i * 16 + r;
         if (m >= M) continue;
 #pragma unroll
         for (int j = 0; j < WN; ++j) {

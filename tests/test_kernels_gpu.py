@@ -219,9 +219,10 @@ def test_linear(llmie, dtype, M, K, N, trans_b):
 
 
 @pytest.mark.parametrize("M,K,N", [(128, 4096, 12288), (100, 11008, 4096), (96, 4096, 8200), (77, 1024, 8194), (128, 512, 130),
-                                   (65, 4096, 22016), (200, 2048, 8448)])
+                                   (65, 4096, 22016), (200, 2048, 8448),
+                                   (64, 4096, 12288), (33, 11008, 4096), (50, 1024, 8194), (40, 4096, 22016), (64, 512, 130)])
 def test_linear_128_row_splitk(llmie, M, K, N):
-    """64 < M <= 128 rows per pass take the LDS-DMA split-K kernel (gemm_mid.cuh): 256- and 128-row weight tiles, ragged K
+    """32 < M <= 128 rows per pass take the LDS-DMA split-K kernel (gemm_mid.cuh; 64- and 128-row activation tiles): 256- and 128-row weight tiles, ragged K
     slices (64 k-tiles over 5 slices), ragged N tiles, N % 4 != 0 (scalar slab stores), clamped activation rows, two passes"""
     rng = np.random.default_rng(M + N)
     x, w = rnd(rng, (M, K), 1.0, torch.float16), rnd(rng, (N, K), 1.0 / np.sqrt(K), torch.float16)
