@@ -13,6 +13,9 @@ the C ABI (include/llmie.h), captured once in a hipGraph and replayed.
 
 N > 1 = N independent data-parallel replicas (one process per GPU, no collective on the data
 path; torch.distributed/gloo only for the start/stop barrier and the MAX over ranks).
+`python bench.py --gpus N` WITHOUT a launcher (no WORLD_SIZE in the environment) spawns the N replicas
+itself: the parent never imports torch or touches a GPU, it starts N fresh child processes pinned one
+per device with HIP_VISIBLE_DEVICES=i (RANK/WORLD_SIZE/MASTER_* set), waits, and relays rank 0's line.
 
 Prints ONE JSON line (rank 0).  Extra keys beside the driver contract:
   roofline      dominant kernel (gate/up GEMV + SwiGLU): algorithmic bytes per launch / mean launch
@@ -178,6 +181,51 @@ def replica_aggregate(elapsed_s, tokens_this_rank, world):
     return float(n.item()) / float(t.item()), float(t.item())
 
 
+def replica_gather(value, world):
+    """every rank's scalar, in rank order (gloo all_gather of CPU tensors; control plane only)"""
+    if world <= 1:
+        return [float(value)]
+    import torch
+    import torch.distributed as dist
+    mine = torch.tensor([float(value)], dtype=torch.float64)
+    out = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
+def replica_env(rank, world, port, base_env):
+    """environment of replica `rank`: pinned to device `rank` (it sees exactly one GPU, its cuda:0)"""
+    env = dict(base_env)
+    env.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HIP_VISIBLE_DEVICES=str(rank), LLMIE_REPLICA_PINNED="1")
+    env.pop("CUDA_VISIBLE_DEVICES", None)
+    env.pop("ROCR_VISIBLE_DEVICES", None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def launch_replicas(n, argv):
+    """Parent of `python bench.py --gpus N` (no launcher): N fresh child processes, one per device.  Nothing here imports
+    torch or initialises the GPU (a process that has must never exec/re-exec).  Returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=replica_env(r, n, port, os.environ),
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,7 +237,13 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the int8/int4/short-context side measurements")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="replica plumbing only (no GPU, no kernels): simulated per-rank times through the real launcher/aggregation")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the parent of N pinned replicas BEFORE torch / the GPU is touched
+        raise SystemExit(launch_replicas(args.gpus, sys.argv[1:]))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -199,9 +253,26 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if args.dry_run:
+        # no kernels: rank r "takes" 0.10 + 0.05 r seconds for batch * steps tokens; everything after that is the real path
+        el_r, tok_r = 0.10 + 0.05 * rank, args.batch * args.steps
+        value, elapsed = replica_aggregate(el_r, tok_r, world)
+        per = replica_gather(tok_r / el_r, world)
+        devs = replica_gather(float(os.environ.get("HIP_VISIBLE_DEVICES", "-1") or -1), world)
+        if rank == 0:
+            print(json.dumps({"metric": "decode_tokens_per_s", "value": round(value, 4), "unit": "tokens/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                              "higher_is_better": True, "scaling": "weak", "dry_run": True,
+                              "per_replica_tokens_per_s": [round(v, 4) for v in per],
+                              "replica_devices": [int(d) for d in devs],
+                              "scaling_efficiency": round(value / (world * per[0]), 4)}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
-    torch.cuda.set_device(local_rank if world > 1 else 0)
+    # launched by torchrun: one visible node, device = LOCAL_RANK; launched by launch_replicas: pinned, the only device is 0
+    torch.cuda.set_device(0 if (world == 1 or os.environ.get("LLMIE_REPLICA_PINNED")) else local_rank)
     llmie = load_llmie()
     llmie.lib()  # fail loudly if the HIP library is missing
 
@@ -280,6 +351,16 @@ def main():
         t1 = time.perf_counter()
         if sync_ranks:
             barrier()
+        solo = None
+        if sync_ranks and world > 1:
+            # the same K steps on rank 0 ALONE (the other replicas idle at the barrier): the one-replica reference the
+            # scaling efficiency of this job is quoted against
+            if rank == 0:
+                ts0 = time.perf_counter()
+                run(K)
+                torch.cuda.synchronize()
+                solo = time.perf_counter() - ts0
+            barrier()
         prof = None
         if profile_steps:
             # per-kernel timing with hipEvents on the launch stream (eager launches of the same step)
@@ -295,11 +376,12 @@ def main():
         dec.close()
         del graph, kc, vc
         torch.cuda.empty_cache()
-        return t1 - t0, prof
+        return t1 - t0, prof, solo
 
     P = 4
-    elapsed, prof = run_decode("f16", weights["layers"], B, S, K, W, P, True)
-    value, elapsed = replica_aggregate(elapsed, B * K, world)
+    own_elapsed, prof, solo_elapsed = run_decode("f16", weights["layers"], B, S, K, W, P, True)
+    value, elapsed = replica_aggregate(own_elapsed, B * K, world)
+    per_replica = replica_gather(B * K / own_elapsed, world)
     ms_per_step = elapsed / K * 1e3
 
     breakdown = {op: dict(us_per_launch=round(ms / n * 1e3, 2), launches_per_step=n // P,
@@ -337,14 +419,19 @@ def main():
                    "graph": not args.no_graph, "layers": cfg["num_layers"]},
         "metric_full": "decode tokens/s + prefill tokens/s, Llama-2-7B fp16 & int8, 1 MI355X",
         "roofline": roofline, "whole_step": whole, "breakdown": breakdown,
+        "per_replica_tokens_per_s": [round(v, 2) for v in per_replica],
     }
+    if world > 1 and solo_elapsed:
+        # whole job / (N x one replica running alone on this node), both measured inside this run
+        out["solo_replica_tokens_per_s"] = round(B * K / solo_elapsed, 2)
+        out["scaling_efficiency"] = round(value / (world * (B * K / solo_elapsed)), 4)
     # ---- other configurations of the metric (rank 0, single GPU only; not the headline value) ----
     if rank == 0 and world == 1 and not args.no_extra:
         extra = {}
 
         def record(name, wfmt, layers, b, s, wbytes, kv_fp8=False):
             k, w_ = min(K, 32), min(W, 4)
-            el, _ = run_decode(wfmt, layers, b, s, k, w_, 0, False, kv_fp8)
+            el, _, _ = run_decode(wfmt, layers, b, s, k, w_, 0, False, kv_fp8)
             ms = el / k * 1e3
             nbytes = decode_bytes_per_step(cfg, b, s, wbytes, 1 if kv_fp8 else 2)
             extra[name] = dict(tokens_per_s=round(b * k / el, 1), ms_per_step=round(ms, 4), batch=b, ctx=s,
