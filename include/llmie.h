@@ -49,6 +49,14 @@ typedef enum {
 
 typedef void *llmie_stream; /* hipStream_t */
 
+typedef enum {
+    LLMIE_W_F16 = 0,     /* fp16 weights [N,K]                                   */
+    LLMIE_W_INT8 = 1,    /* int8 [N,K] + fp16 per-row scale                      */
+    LLMIE_W_INT4 = 2,    /* packed int4 [N,K/2] + fp16 scale per (row, group)    */
+    LLMIE_W_FP8 = 3,     /* e4m3 [N,K] + fp32 per-row scale                      */
+    LLMIE_W_F32 = 4      /* fp32 weights (dtype LLMIE_F32 engines only)          */
+} llmie_weight_format;
+
 int llmie_abi_version(void);
 const char *llmie_last_error(void);
 /* "gfx950" -- the only architecture this library carries code objects for */
@@ -228,19 +236,43 @@ int llmie_quantize_w4(const void *w, uint8_t *wq, void *scale, int N, int K, int
                       llmie_stream stream);
 int llmie_quantize_fp8(const void *w, uint8_t *wq, float *scale, int N, int K, llmie_stream stream);
 
+/* Tile-packed weight images for decode batches (no reference counterpart: the reference streams row-major weights through
+ * cuBLAS, src/kernels/linear.cu:10-87).  An MFMA operand wants 16 different weight rows across the lanes of one load, a
+ * DRAM stream wants one contiguous KiB per wave instruction; the packed image gives both: tile = 16 rows, block = KB
+ * consecutive k of the tile = 1 KiB in MFMA fragment order (KB = 32 fp16, 64 int8 / e4m3, 128 int4); K % KB == 0, rows
+ * past N are zero.  swiglu_pairs != 0: w is a fused gate_up matrix [2I, K], packed tile 2p = gate rows [16p, 16p+16),
+ * tile 2p+1 = the matching up rows.  int4: the group-128 scales are re-laid [tile][block][16] fp16 into packed_scale
+ * (llmie_packed_scale_bytes; 0 for the other formats, which keep their per-row scale vector as it is).
+ * llmie_linear_packed: y[M, N] (or [M, N/2] for swiglu != 0) = [swiglu]( rmsnorm(x + pre_bias) * gamma . W^T ) (+ residual),
+ * 1 <= M <= 32 fp16 rows; gamma == NULL: no norm.  x is read once per workgroup into registers (8 waves split K), the
+ * weights stream through a per-wave LDS-DMA ring.  workspace: llmie_linear_packed_workspace_bytes() bytes (non-zero only where K
+ * exceeds the register-resident slice, e.g. the 7B down projection: fp32 split-K slabs + one reduce launch).
+ */
+size_t llmie_packed_weight_bytes(llmie_weight_format fmt, int N, int K, int swiglu_pairs);
+size_t llmie_packed_scale_bytes(llmie_weight_format fmt, int N, int K, int swiglu_pairs);
+int llmie_pack_weight(llmie_weight_format fmt, const void *w, const void *scale, void *packed, void *packed_scale,
+                      int N, int K, int swiglu_pairs, llmie_stream stream);
+size_t llmie_linear_packed_workspace_bytes(llmie_weight_format fmt, int M, int K, int N);
+/* x32_flags: which operands are in the fragment-ordered activation layout "x32" instead of row-major (LLMIE_X32_X = x,
+ * LLMIE_X32_Y = y, LLMIE_X32_RES = residual): a [<= 32 rows, C] fp16 matrix, C % 32 == 0, stored
+ * [C / 32][2 row tiles][64 lanes][8 halves], lane = 16 * ((c % 32) / 8) + (m % 16), i.e. element (m, c) at half offset
+ * ((c / 32) * 2 + m / 16) * 512 + ((c % 32) / 8) * 128 + (m % 16) * 8 + c % 8; always 32 rows of storage
+ * (llmie_x32_bytes(C) = 64 C bytes).  Each (32 columns, 16 rows) piece is the 1 KiB MFMA operand of the consumer, so a
+ * kernel chain that keeps its activations in x32 loads them with contiguous KiB reads and no transposition;
+ * llmie_x32_convert moves a matrix between the two layouts (to_x32 != 0: rows >= M are zero-filled). */
+enum { LLMIE_X32_X = 1, LLMIE_X32_Y = 2, LLMIE_X32_RES = 4 };
+size_t llmie_x32_bytes(int C);
+int llmie_x32_convert(const void *src, void *dst, int M, int C, int to_x32, llmie_stream stream);
+int llmie_linear_packed(llmie_weight_format fmt, const void *x, const void *packed, const void *scale, void *y,
+                        int M, int K, int N, int swiglu, int x32_flags, const void *residual, const void *gamma,
+                        const void *pre_bias, float eps, void *workspace, size_t workspace_bytes,
+                        llmie_stream stream);
+
 /* ------------------------------------------------------------------------- */
 /* 3. fused decoder engine (what LlamaSelfDecoder<T>::forward and             */
 /*    LlamaModel<T>::generateNextToken run on; src/layers/self_decoder.cpp:24-122, */
 /*    src/models/llama/llama.cpp:219-318)                                     */
 /* ------------------------------------------------------------------------- */
-
-typedef enum {
-    LLMIE_W_F16 = 0,     /* fp16 weights [N,K]                                   */
-    LLMIE_W_INT8 = 1,    /* int8 [N,K] + fp16 per-row scale                      */
-    LLMIE_W_INT4 = 2,    /* packed int4 [N,K/2] + fp16 scale per (row, group)    */
-    LLMIE_W_FP8 = 3,     /* e4m3 [N,K] + fp32 per-row scale                      */
-    LLMIE_W_F32 = 4      /* fp32 weights (dtype LLMIE_F32 engines only)          */
-} llmie_weight_format;
 
 typedef enum { LLMIE_KV_NATIVE = 0, LLMIE_KV_FP8 = 1 } llmie_kv_format;
 

@@ -66,6 +66,13 @@ _SIGS = {
     "llmie_linear_fp8": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp],
     "llmie_linear_fp8_workspace_bytes": [_i, _i],
     "llmie_linear_fp8_swiglu": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp],
+    "llmie_packed_weight_bytes": [_i, _i, _i, _i],
+    "llmie_packed_scale_bytes": [_i, _i, _i, _i],
+    "llmie_pack_weight": [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "llmie_linear_packed_workspace_bytes": [_i, _i, _i, _i],
+    "llmie_linear_packed": [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _sz, _vp],
+    "llmie_x32_bytes": [_i],
+    "llmie_x32_convert": [_vp, _vp, _i, _i, _i, _vp],
     "llmie_quantize_w8": [_vp, _vp, _vp, _i, _i, _vp],
     "llmie_quantize_w4": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "llmie_quantize_fp8": [_vp, _vp, _vp, _i, _i, _vp],
@@ -90,6 +97,10 @@ _SIGS = {
 _RESTYPES = {
     "llmie_decoder_mha_workspace_bytes": _sz,
     "llmie_linear_fp8_workspace_bytes": _sz,
+    "llmie_packed_weight_bytes": _sz,
+    "llmie_x32_bytes": _sz,
+    "llmie_packed_scale_bytes": _sz,
+    "llmie_linear_packed_workspace_bytes": _sz,
     "llmie_decoder_workspace_bytes": _sz,
     "llmie_decoder_prefill_workspace_bytes": _sz,
     "llmie_decoder_create": _vp,
@@ -458,3 +469,42 @@ def linear_fp8(x, wq, wscale, y, workspace, bias=None, residual=None):
                                   _p(residual), _p(workspace), workspace.numel() * workspace.element_size(), _st()),
            "linear_fp8")
     return y
+
+
+# ---- tile-packed weight images + batch-decode linear on them (include/llmie.h section 2) ----
+def pack_weight(fmt, w, scale=None, swiglu_pairs=False):
+    """row-major weights (fmt's storage, [N, K] logical) -> (packed image uint8 tensor, packed int4 group scales or None)"""
+    import torch
+    N = w.shape[0]
+    K = w.shape[1] * (2 if fmt == W_INT4 else 1)
+    nbytes = lib().llmie_packed_weight_bytes(fmt, N, K, int(swiglu_pairs))
+    if nbytes == 0:
+        raise LlmieError("pack_weight: shape N=%d K=%d not packable in format %d" % (N, K, fmt))
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    sbytes = lib().llmie_packed_scale_bytes(fmt, N, K, int(swiglu_pairs))
+    pscale = torch.empty(sbytes, dtype=torch.uint8, device=w.device) if sbytes else None
+    _check(lib().llmie_pack_weight(fmt, _p(w), _p(scale), _p(packed), _p(pscale), N, K, int(swiglu_pairs), _st()), "pack_weight")
+    return packed, pscale
+
+
+X32_X, X32_Y, X32_RES = 1, 2, 4
+
+
+def linear_packed(fmt, x, packed, scale, y, N, swiglu=False, residual=None, gamma=None, pre_bias=None, eps=0.0, M=None, K=None,
+                  x32_flags=0):
+    """y = [swiglu](rmsnorm(x + pre_bias) * gamma . W^T) (+ residual) on a packed image; scale = per-row (int8 / fp8) or the
+    packed group scales (int4).  x32_flags: operands in the x32 activation layout (pass M, K explicitly for an x32 x)"""
+    import torch
+    if M is None:
+        M, K = x.shape
+    ws_bytes = lib().llmie_linear_packed_workspace_bytes(fmt, M, K, N)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    _check(lib().llmie_linear_packed(fmt, _p(x), _p(packed), _p(scale), _p(y), M, K, N, int(swiglu), int(x32_flags), _p(residual),
+                                     _p(gamma), _p(pre_bias), float(eps), _p(ws), ws_bytes, _st()), "linear_packed")
+    return y
+
+
+def x32_convert(src, dst, M, C, to_x32):
+    """row-major [M, C] fp16 <-> x32 image (llmie_x32_bytes(C) bytes)"""
+    _check(lib().llmie_x32_convert(_p(src), _p(dst), M, C, int(to_x32), _st()), "x32_convert")
+    return dst

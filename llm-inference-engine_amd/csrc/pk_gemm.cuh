@@ -1,0 +1,790 @@
+// Batch-decode projections on PRE-PACKED weights (4 < M <= 32 token rows): y = x . W^T for launchLinearGemm
+// (src/kernels/linear.cu:10-87) at decode batch sizes, HBM-bound (bytes = N*K*w per launch).
+//
+// Why a packed copy: an MFMA A operand wants 16 DIFFERENT weight rows across the lanes of one load, a DRAM stream
+// wants the lanes of one load on ONE contiguous KiB.  With row-major weights those two exclude each other (the round-1
+// split-K kernel bought the contiguity back with a per-wave LDS transposer and still streamed at 2-3.6 TB/s).  The
+// MI355X has 288 GB of HBM, so the engine keeps a second, tile-packed image of every matrix it streams at these batch
+// sizes: tile = 16 weight rows, block = KB consecutive k of those 16 rows = exactly 1 KiB laid out so that lane l of a
+// wave reads its 16 bytes at offset 16*l and owns row (l & 15), k-group (l >> 4) -- the MFMA fragment itself.  A tile is
+// nblk contiguous KiB: every wave instruction is one contiguous KiB and consecutive instructions continue the stream.
+//
+//   block image [q = 0..3][r = 0..15][16 bytes]  (lane l = 16 q + r), per format:
+//     fp16        KB = 32 : bytes = W[r][32 j + 8 q + (0..7)]                                  1 MFMA step / block
+//     int8 / e4m3 KB = 64 : bytes 8 s + e = W[r][64 j + 32 s + 8 q + e], s = 0,1              2 steps / block
+//     int4        KB = 128: word s = W[r][128 j + 32 s + 8 q + (0..7)], s = 0..3, nibbles placed so that the
+//                           0x6400-magic unpack yields natural k order                        4 steps / block
+//
+// Kernel (the M = 1 K-split GEMV's structure, with MFMA in place of the dot products): ONE 512-thread workgroup per CU,
+// persistent over 16-row tiles; its 8 waves split K, so the activation slice a wave multiplies is fixed for the whole
+// launch and lives in REGISTERS as ready-made B fragments (loaded once, the fused RMSNorm applied in place) -- no
+// activation staging, no barrier in front of the stream.  Per tile a wave loads XBLK contiguous KiB (ring of 16 loads in
+// flight per lane, refilled as each register is consumed), de-quantises in registers, issues 2 * MT MFMAs per block,
+// and the 8 partial tiles meet in LDS once per tile (double-buffered slot, one barrier per tile, like the GEMV).  The
+// epilogue (row scale, bias, residual, SwiGLU over a gate tile and its up tile, or fp32 split-K slabs) runs in registers
+// of the first MT waves: no fp32 slab round trip except where K itself is split over workgroups (down projection).
+#pragma once
+#include "gemm_kernels.cuh"
+
+#include <type_traits>
+#include <utility>
+
+namespace llmie {
+
+enum : int { PK_F16 = 16, PK_I8 = 8, PK_I4 = 4, PK_FP8 = 108 };
+enum : int { PK_EPI_PLAIN = 0, PK_EPI_SWIGLU = 1, PK_EPI_SLAB = 2 };
+enum : int { PK_X32_X = 1, PK_X32_Y = 2, PK_X32_RES = 4 };   // which operands of a call are in the x32 activation layout
+constexpr int PK_NORM_MAX_K = 8192;   // fused-norm prologue: gamma / pre_bias staged in LDS by 2 chunks per thread
+
+template <int WF> struct PkFmt;
+template <> struct PkFmt<PK_F16> {
+    static constexpr int KB = 32, SPB = 1, XBLK = 16;
+};
+template <> struct PkFmt<PK_I8> {
+    static constexpr int KB = 64, SPB = 2, XBLK = 8;
+};
+template <> struct PkFmt<PK_FP8> {
+    static constexpr int KB = 64, SPB = 2, XBLK = 8;
+};
+template <> struct PkFmt<PK_I4> {
+    static constexpr int KB = 128, SPB = 4, XBLK = 4;
+};
+
+struct PkArgs {
+    const half_t *x;             // [M, K] fp16
+    const unsigned char *Wp;     // packed image: [tiles][nblk][1 KiB]
+    int M, K, N;                 // N = logical output features (PLAIN / SLAB) or 2 * inter (SWIGLU)
+    int units;                   // work units along N: tiles (PLAIN / SLAB) or gate/up tile pairs (SWIGLU)
+    int nblk;                    // K / KB
+    int bps;                     // blocks per K slice (gridDim.y slices)
+    half_t *y;                   // PLAIN: [M, N]; SWIGLU: [M, N/2]
+    float *slab;                 // SLAB: [gridDim.y][M][N] fp32 partial sums (unscaled)
+    const void *scale;           // int8: fp16 [N] per row; fp8: fp32 [N]; int4: packed group scales [tiles][nblk][16] fp16
+    const half_t *residual;      // [M, N] or null (PLAIN; may alias y)
+    int x_x32, y_x32, res_x32;   // x / y / residual are in the fragment-ordered "x32" activation layout (below) instead of row-major
+    const half_t *gamma;         // [K]: rmsnorm(x + pre_bias) * gamma fused in front (gridDim.y == 1 only), or null
+    const half_t *pre_bias;      // [K] or null
+    float eps;
+};
+
+// "x32" activation layout of a [<= 32 rows, K] fp16 matrix, K % 32 == 0: [K / 32][2 row tiles][64 lanes][8 halves], lane =
+// 16 * ((k % 32) / 8) + (m % 16) -- each (32 k, 16 rows) piece is the 1 KiB MFMA B fragment of a 16x16x32 step, so a consumer
+// wave loads its operand registers with contiguous KiB reads and no transposition (measured: fragment-shaped loads of a
+// row-major matrix are TA-bound, row-contiguous loads + an LDS transposition cost ~1 us of a 32-row prologue).  The engine
+// keeps its internal activations (residual stream, attention output, SwiGLU output) in this layout between the packed
+// kernels; rows >= M of a tile are never read as data (the consumer zeroes them).  Always 32 rows of storage: K * 64 bytes.
+__host__ __device__ inline size_t x32_offset(int m, int k) {
+    return (static_cast<size_t>(k >> 5) * 2 + (m >> 4)) * 512 + ((k & 31) >> 3) * 128 + (m & 15) * 8 + (k & 7);
+}
+
+// A fragment of MFMA step s from one 16-byte packed chunk
+template <int WF> __device__ __forceinline__ half8_t pk_afrag(const uint4_t &w, const int s) {
+    if constexpr (WF == PK_F16) {
+        return __builtin_bit_cast(half8_t, w);
+    } else if constexpr (WF == PK_I8) {
+        return dequant_i8x8(w[2 * s], w[2 * s + 1]);
+    } else {
+        // int4 word: nibble i at bits 4i.  (w & 0x000F000F)|0x6400.. = (1024 + n0, 1024 + n4); bits 4-7 land 16x higher and
+        // come back with one packed fma (x/16 - 72 = n - 8); a shift by 8 exposes n2,n6 / n3,n7 to the same masks.
+        // The packer stores k = 0..7 of the step as nibbles (n0,n4,n1,n5,n2,n6,n3,n7): the result is in natural k order.
+        const half2_t off8 = {static_cast<half_t>(1032.f), static_cast<half_t>(1032.f)};
+        const half2_t sixteenth = {static_cast<half_t>(0.0625f), static_cast<half_t>(0.0625f)};
+        const half2_t off72 = {static_cast<half_t>(72.f), static_cast<half_t>(72.f)};
+        const unsigned int w0 = w[s], w8 = w0 >> 8;
+        const half2_t h0 = as_half2((w0 & 0x000F000Fu) | 0x64006400u) - off8;
+        const half2_t h1 = as_half2((w0 & 0x00F000F0u) | 0x64006400u) * sixteenth - off72;
+        const half2_t h2 = as_half2((w8 & 0x000F000Fu) | 0x64006400u) - off8;
+        const half2_t h3 = as_half2((w8 & 0x00F000F0u) | 0x64006400u) * sixteenth - off72;
+        return half8_t{h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
+    }
+}
+
+// ---- loads of the kernel ----
+// (Every asm statement with an SGPR base opens with s_nop 4: hipcc pads no hazard inside an asm string, and under register
+// pressure it restores a spilled SGPR with v_readlane right in front of the statement -- "VALU writes SGPR -> VMEM reads it"
+// needs 5 wait states (cdna_hip_programming.md 5.7 item 2).  Without the pad a load used a stale base: GPU memory fault.)
+// Weights: LDS-DMA (global_load_lds_dwordx4, one KiB per wave instruction, no VGPR destination) into a per-wave ring of D
+// one-KiB slots, consumed D blocks later with a hand-counted s_waitcnt vmcnt(D - 1) and one ds_read_b128.  Two earlier
+// forms of this kernel kept the ring in registers: (1) with hipcc-visible loads the compiler's vmcnt bookkeeping merges
+// every path through the loop (refill / no-refill tails, the epilogue branch) to the most conservative count and drained
+// the whole ring at the top of every tile; (2) with the loads hidden in asm the counts were exact, but a 64-register ring
+// beside the 128 registers of B fragments left hipcc no slack at 32 rows: spills of registers whose asm load was still in
+// flight, and loop-carried moves of them, store / copy garbage (NaN at M = 32).  A ring in LDS has neither problem, costs
+// one ds_read per KiB, and its depth is set by LDS capacity (96 KiB in flight per CU), not by registers.
+// Activations / gamma / epilogue operands: asm loads in the PROLOGUE only (issued before the first DMA, one exact wait), so
+// the loop contains no VGPR-returning global load at all; the only VMEM operations hipcc sees there are the epilogue
+// stores, which nobody waits for (an op issued behind a DMA makes a counted wait retire one more DMA than needed, never
+// one less).
+__device__ __forceinline__ void pk_gload16_s(uint4_t &dst, const unsigned voff, const void *sbase) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+// one KiB per wave: 16 bytes per lane from sbase + voff (sbase wave-uniform: scalar pointer arithmetic only, no VALU) -> LDS
+// lds_dst + 16 lane (M0 = wave-uniform LDS byte address, written in the same statement that uses it: hipcc does not preserve M0
+// for asm and keeps nothing of its own there in this kernel -- no DMA builtin, no indirect register indexing).  In asm, not the
+// builtin: hipcc orders every LDS write of its own behind a pending builtin DMA with s_waitcnt vmcnt(0) (measured here: each
+// table store of the prologue drained the ring fill).
+__device__ __forceinline__ void pk_dma16_nt(const unsigned voff, const void *sbase, const unsigned lds_dst) {
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void pk_gload16(uint4_t &dst, const void *p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void pk_gload8(uint2 &dst, const void *p) {
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N> __device__ __forceinline__ void pk_vmwait() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// the register was written by an asm load that the wait above has retired: nothing that reads it may move above this point
+__device__ __forceinline__ void pk_landed(uint4_t &r) { asm volatile("" : "+v"(r)::"memory"); }
+__device__ __forceinline__ void pk_landed(uint2 &r) { asm volatile("" : "+v"(r)::"memory"); }
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ... (register arrays indexed by the loop variable stay registers)
+template <typename Fn, int... Is> __device__ __forceinline__ void pk_static_for_impl(Fn &&f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename Fn> __device__ __forceinline__ void pk_static_for(Fn &&f) {
+    pk_static_for_impl(static_cast<Fn &&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// Workgroup barrier that leaves the LDS-DMA ring in flight: __syncthreads() would make hipcc drain vmcnt to 0 while a
+// global_load_lds is pending (cdna_hip_programming.md 5, "Pipelining across barriers"); LDS traffic of this wave is complete
+// (lgkmcnt 0) before it arrives, the asm memory clobbers keep the compiler from moving LDS accesses across.
+__device__ __forceinline__ void pk_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+#ifdef PK_STAMPS   // diagnostic build only (tools/pkstamps.py): where a workgroup's time goes; never defined in the product build
+__device__ unsigned long long pk_stamp_buf[256 * 8 * 16];
+#define PK_STAMP(i) do { if (lane == 0) pk_stamp_buf[(blockIdx.x * 8 + wave) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PK_STAMP(i) do { } while (0)
+#endif
+
+constexpr int PK_MAX_UNITS = 16;   // work units per workgroup whose epilogue operands are pre-staged in LDS
+__host__ __device__ constexpr int pk_ring_depth(int epi) { return epi == PK_EPI_SWIGLU ? 11 : 12; }
+// LDS carve (bytes), shared by the kernel and the host launcher
+struct PkLds {
+    int red, ring, etab, rtab, total;
+};
+__host__ __device__ constexpr PkLds pk_lds(int mt, int epi, int norm_k /* K if a norm is fused, else 0 */, bool resid) {
+    const int tpi = epi == PK_EPI_SWIGLU ? 2 : 1;
+    int red = 2 * 8 * tpi * mt * 1024;                     // [2 parities][8 waves][tpi * mt tiles][64 lanes] floatx4
+    const int stage = 8 * mt * 16 * 4 + 4 * norm_k;        // prologue only, aliases `red`: norm / amax statistics + gamma + pre_bias
+    if (stage > red) red = stage;
+    if (red < 8 * 4096) red = 8 * 4096;                    // prologue only, aliases `red`: one 4 KiB transposition patch per wave
+    const int ring = 8 * pk_ring_depth(epi) * 1024;
+    const int etab = epi == PK_EPI_SLAB ? 0 : PK_MAX_UNITS * tpi * 16 * 4;   // row scales (fp32) of every unit of the workgroup
+    const int rtab = resid ? PK_MAX_UNITS * mt * 16 * 16 * 2 : 0;            // residual pieces [unit][mt * 16 rows][16] fp16
+    return PkLds{red, ring, etab, rtab, red + ring + etab + rtab};
+}
+
+template <int MT, int WF, int EPI, bool XL /* x is in the x32 layout */>
+__global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
+    using F = PkFmt<WF>;
+    constexpr int NW = 8, KB = F::KB, SPB = F::SPB, XBLK = F::XBLK;
+    constexpr bool FP8 = WF == PK_FP8, I4 = WF == PK_I4;
+    constexpr int TPI = EPI == PK_EPI_SWIGLU ? 2 : 1;   // tiles per work unit
+    constexpr int D = pk_ring_depth(EPI);
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pk_smem[];
+    const PkLds lay = pk_lds(MT, EPI, a.gamma ? a.K : 0, EPI == PK_EPI_PLAIN && a.residual != nullptr);
+    floatx4 *red = reinterpret_cast<floatx4 *>(pk_smem);                 // [2][NW][TPI * MT][64]
+    float *stat = reinterpret_cast<float *>(pk_smem);                     // prologue only (aliases red): [NW][MT][16]
+    half_t *gam = reinterpret_cast<half_t *>(pk_smem + NW * MT * 16 * 4); // prologue only: gamma [K], pre_bias [K]
+    unsigned char *ring_all = pk_smem + lay.red;
+    float *etab = reinterpret_cast<float *>(pk_smem + lay.red + lay.ring);           // [units][TPI][16]
+    half_t *rtab = reinterpret_cast<half_t *>(pk_smem + lay.red + lay.ring + lay.etab);  // [units][MT * 16][16]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: K range, block addresses stay scalar
+    const int r = lane & 15, q = lane >> 4;
+    // ---- this wave's K range: blocks [blk0, blk0 + cnt) of slice blockIdx.y ----
+    const int nb0 = blockIdx.y * a.bps, nb1 = min(a.nblk, nb0 + a.bps), nbs = nb1 - nb0;
+    const int per = nbs / NW, rem = nbs - per * NW;
+    const int cnt = per + (wave < rem ? 1 : 0);                  // 0 <= cnt <= XBLK
+    const int blk0 = nb0 + wave * per + min(wave, rem);
+    auto blkc = [&](int u) { return min(blk0 + u, nb1 - 1); };   // in-bounds address for a slot the wave does not own (zero x)
+
+    // ---- work units of this workgroup: blockIdx.x, + gridDim.x, ... ; its tile stream has L = iters * TPI elements ----
+    if (static_cast<int>(blockIdx.x) >= a.units) return;
+    const int iters = (a.units - static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
+    const int L = iters * TPI;
+    auto unit_at = [&](int it) { return it * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x); };
+    // this wave's block stream: element k = (tile i = k / cnt, block u = k % cnt), T = L * cnt elements
+    const int T = L * cnt;
+    unsigned char *ring = ring_all + wave * (D * 1024);
+    const unsigned woff = lane * 16;
+    const unsigned ring_lds = static_cast<unsigned>(reinterpret_cast<size_t>((lptr_t)ring));   // LDS byte address, wave-uniform
+    // DMA source of the NEXT stream element to fetch: a running scalar pointer (no multiplications in the loop).  Inside a
+    // tile the wave's blocks are contiguous KiB; from its last block the pointer steps to the wave's first block of the next
+    // tile of the unit, or of the workgroup's next unit.
+    const size_t tile_bytes = static_cast<size_t>(a.nblk) * 1024;
+    const long step_in = static_cast<long>(tile_bytes) - static_cast<long>(cnt) * 1024;
+    const long step_unit = static_cast<long>(static_cast<size_t>(gridDim.x) * TPI - (TPI - 1)) * static_cast<long>(tile_bytes) - static_cast<long>(cnt) * 1024;
+    const unsigned char *src = a.Wp + (static_cast<size_t>(unit_at(0)) * TPI * a.nblk + blk0) * 1024;
+    int ri = 0, ru = 0;   // (tile, block) of the next stream element to fetch
+    // fetch the next stream element into ring slot byte offset `sb` and advance the source
+    auto dma_next = [&](const unsigned sb) {
+        pk_dma16_nt(woff, src, ring_lds + sb);
+        src += 1024;
+        if (++ru == cnt) {
+            ru = 0;
+            ++ri;
+            src += (TPI == 2 && (ri & 1)) ? step_in : step_unit;
+        }
+    };
+
+    PK_STAMP(0);
+    // ---- first half of the ring fill goes out before anything else: its HBM latency runs under the issue of the activation
+    //      loads (256 KiB per CU at the L1's 64 bytes per clock = 1.7 us by itself); the second half follows them, so that the
+    //      one prologue wait below (loads retire in order) leaves half a ring in flight for the start of the loop ----
+    constexpr int DH = D / 2;
+    for (int k = 0; k < DH && k < T; ++k) dma_next(k * 1024);
+    // ---- prologue loads (all asm, one wait): activation slice, gamma / pre_bias, epilogue operands ----
+    // Activation slice of this wave = rows [0, 16 MT) x its XBLK blocks.  Fragment-shaped global loads (16 rows x 64 bytes per
+    // wave instruction) are TA-bound (~90 cycles each: this prologue took ~10 us that way), so the slice is fetched in
+    // row-contiguous pieces -- one instruction = 4 rows x 256 bytes (two blocks' worth of k) -- into the SAME registers that
+    // will hold the B fragments, and turned into fragments 4 KiB at a time through a private LDS patch after the wait.
+    //   piece (t, c, i): rows 16 t + 4 i + (lane >> 4), bytes [256 c + 16 (lane & 15), +16) of the slice row   (c = block pair)
+    //   fragment (u, s, t): lane (r, q) <- row 16 t + r, bytes [128 u + 64 s + 16 q, +16)                        (u = 2 c + uu)
+    static_assert(KB * 2 == 128 || WF == PK_F16 || WF == PK_I4, "block = 128 activation bytes per row for the 8-bit formats");
+    constexpr int XB = KB * 2;                 // activation bytes per block and row (fp16 x): 64 / 128 / 256
+    constexpr int PAIRB = 256;                 // bytes of one row piece
+    constexpr int NPAIR = XBLK * XB / PAIRB;   // row pieces per row: 16 * 64 / 256 = 4 (fp16 weights), 8 * 128 / 256 = 4, 4 * 256 / 256 = 4
+    static_assert(NPAIR * 4 == XBLK * SPB, "register count of pieces == fragments");
+    uint4_t xw[XBLK][SPB][MT];
+    auto piece = [&](int t, int c, int i) -> uint4_t & {   // the register that receives piece (t, c, i): any bijection onto xw
+        const int f = c * 4 + i;                            // 0 .. XBLK * SPB - 1
+        return xw[f / SPB][f % SPB][t];
+    };
+    if constexpr (XL) {
+        // fragment (u, s, t) = the KiB at ((kstep * 2 + t) * 1 KiB), kstep = block * SPB + s: one contiguous load each.
+        // Every workgroup of the launch reads the SAME activation image; started in lock step they all sit on the same few L2
+        // channels at any moment (measured: 256 KiB per CU took 3.9 us, half the L2's rate), so the workgroups that share an
+        // XCD (blockIdx / 8 = consecutive CUs of one XCD under round-robin placement -- speed only) start a quarter of the way
+        // around from each other.
+        auto issue_from = [&](auto q0_tag) {
+            constexpr int U0 = decltype(q0_tag)::value * (XBLK / 4);
+            pk_static_for<XBLK>([&](auto v_tag) {
+                constexpr int u = (decltype(v_tag)::value + U0) % XBLK;
+#pragma unroll
+                for (int s2 = 0; s2 < SPB; ++s2)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+                        pk_gload16_s(xw[u][s2][t], woff, reinterpret_cast<const unsigned char *>(a.x) + (static_cast<size_t>(blkc(u)) * SPB + s2) * 2048 + t * 1024);
+            });
+        };
+        switch ((blockIdx.x >> 3) & 3) {
+            case 0: issue_from(std::integral_constant<int, 0>{}); break;
+            case 1: issue_from(std::integral_constant<int, 1>{}); break;
+            case 2: issue_from(std::integral_constant<int, 2>{}); break;
+            default: issue_from(std::integral_constant<int, 3>{}); break;
+        }
+    } else {
+        const size_t slice_bytes = static_cast<size_t>(a.K) * 2;
+        // first byte of the slice inside a row, clamped so that every piece stays inside the row (blocks the wave does not own
+        // are zeroed below)
+        const size_t sb0 = min(static_cast<size_t>(blk0) * XB, slice_bytes - static_cast<size_t>(XBLK) * XB);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned voff = static_cast<unsigned>(min(16 * t + 4 * i + (lane >> 4), a.M - 1)) * static_cast<unsigned>(slice_bytes) + 16 * (lane & 15);
+#pragma unroll
+                for (int c = 0; c < NPAIR; ++c)
+                    pk_gload16_s(piece(t, c, i), voff, reinterpret_cast<const unsigned char *>(a.x) + sb0 + c * PAIRB);
+            }
+    }
+    constexpr int GCH = PK_NORM_MAX_K / 4096;   // gamma / pre_bias: 16-byte chunks per thread
+    uint4_t graw[GCH], praw[GCH];
+    const int kchunks = a.K >> 3;
+    if (a.gamma) {
+#pragma unroll
+        for (int c = 0; c < GCH; ++c) {
+            const unsigned goff = static_cast<unsigned>(min(c * 512 + tid, kchunks - 1)) * 16;
+            pk_gload16_s(graw[c], goff, a.gamma);
+            pk_gload16_s(praw[c], goff, a.pre_bias ? a.pre_bias : a.gamma);
+        }
+    }
+    // epilogue operands of every unit of this workgroup -> LDS tables (the loop then needs no VGPR-returning global load):
+    // thread e of the first `iters * TPI * 4` threads fetches 4 row scales; `iters * MT * 16 * 4`... threads 4 residual halves
+    uint2 escale{0u, 0u};
+    const int n_sc = (EPI == PK_EPI_SLAB || (WF != PK_I8 && !FP8)) ? 0 : iters * TPI * 4;   // items of 4 scales
+    const bool has_res = EPI == PK_EPI_PLAIN && a.residual != nullptr;
+    const int n_rs = has_res ? iters * MT * 16 * 4 : 0;                                         // items of 4 halves
+    uint4_t escale4{0u, 0u, 0u, 0u};
+    if (tid < n_sc) {
+        const int it = tid / (TPI * 4), j = (tid / 4) % TPI, c = tid & 3;
+        int n = 16 * unit_at(it) + 4 * c;                       // PLAIN: feature; SWIGLU: inter index (+ inter for the up tile)
+        if constexpr (EPI == PK_EPI_SWIGLU) n = min(n, (a.N >> 1) - 4) + j * (a.N >> 1);
+        else n = min(n, a.N - 4);
+        if constexpr (FP8) pk_gload16(escale4, reinterpret_cast<const float *>(a.scale) + n);
+        else pk_gload8(escale, reinterpret_cast<const half_t *>(a.scale) + n);
+    }
+    uint2 eres2[4];   // PK_MAX_UNITS * MT * 64 <= 2048 items = 4 rounds of the 512 threads
+    if (has_res) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int e = min(rr * 512 + tid, n_rs - 1);
+            const int it = e / (MT * 64), m = min((e / 4) % (MT * 16), a.M - 1), c = e & 3;
+            const int n = min(16 * unit_at(it) + 4 * c, a.N - 4);
+            pk_gload8(eres2[rr], a.residual + (a.res_x32 ? x32_offset(m, n) : static_cast<size_t>(m) * a.N + n));
+        }
+    }
+    for (int k = DH; k < D && k < T; ++k) dma_next(k * 1024);
+    PK_STAMP(1);
+    if (T >= D) pk_vmwait<D - DH>();   // activations, tables and the first half of the ring have landed
+    else pk_vmwait<0>();
+    PK_STAMP(2);
+    if constexpr (XL) {
+#pragma unroll
+        for (int u = 0; u < XBLK; ++u)
+#pragma unroll
+            for (int s2 = 0; s2 < SPB; ++s2)
+#pragma unroll
+                for (int t = 0; t < MT; ++t) pk_landed(xw[u][s2][t]);
+    } else {
+        // pieces -> fragments through this wave's 4 KiB patch of the (still unused) reduction region: [16 rows][16 chunks] of 16
+        // bytes, chunk index XOR row (conflict-free 16-row column reads); same-wave LDS operations execute in order
+        unsigned char *patch = pk_smem + wave * 4096;
+        const int own0 = blk0 - static_cast<int>(min(static_cast<size_t>(blk0) * XB, static_cast<size_t>(a.K) * 2 - static_cast<size_t>(XBLK) * XB) / XB);
+        // own0 = index, inside the fetched window, of the wave's first own block (0 unless the window was clamped at the row end)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int c = 0; c < NPAIR; ++c) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 4 * i + (lane >> 4);
+                    pk_landed(piece(t, c, i));
+                    *reinterpret_cast<uint4_t *>(patch + row * 256 + (((lane & 15) ^ row) << 4)) = piece(t, c, i);
+                }
+                asm volatile("" ::: "memory");
+                // the 4 fragments this 256-byte column range holds, back into the same 4 registers: fragment f = 4 c + j is
+                // (window block f / SPB, step f % SPB); lane (r, q) takes chunk 4 j + q of row r
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    piece(t, c, j) = *reinterpret_cast<const uint4_t *>(patch + r * 256 + (((j * 4 + q) ^ r) << 4));
+                asm volatile("" ::: "memory");
+            }
+        // window block wb = own block u + own0: shift down (own0 > 0 only for the last wave(s) of a clamped window)
+        if (own0 > 0) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int sft = 0; sft < XBLK; ++sft) {   // at most XBLK - 1 single-block shifts
+                    if (sft < own0) {
+#pragma unroll
+                        for (int u = 0; u + 1 < XBLK; ++u)
+#pragma unroll
+                            for (int s2 = 0; s2 < SPB; ++s2) xw[u][s2][t] = xw[u + 1][s2][t];
+                    }
+                }
+        }
+    }
+    // zero what the wave does not own / rows past M (wave-uniform test; the common full case skips 128 selects)
+    if (cnt < XBLK || a.M < 16 * MT) {
+#pragma unroll
+        for (int u = 0; u < XBLK; ++u)
+#pragma unroll
+            for (int s2 = 0; s2 < SPB; ++s2)
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    if (!(u < cnt && 16 * t + r < a.M)) xw[u][s2][t] = uint4_t{0u, 0u, 0u, 0u};
+    }
+    PK_STAMP(3);
+    if (a.gamma || FP8) pk_barrier();   // the patches alias the statistics / gamma staging written below
+    PK_STAMP(4);
+    auto xfrag = [&](const uint4_t &v) { return __builtin_bit_cast(half8_t, v); };
+    if (tid < n_sc) {
+        if constexpr (FP8) {
+            pk_landed(escale4);
+            *reinterpret_cast<uint4_t *>(etab + tid * 4) = escale4;
+        } else {
+            pk_landed(escale);
+            const half4_t h = __builtin_bit_cast(half4_t, escale);
+            *reinterpret_cast<floatx4 *>(etab + tid * 4) = floatx4{to_f32(h[0]), to_f32(h[1]), to_f32(h[2]), to_f32(h[3])};
+        }
+    }
+    if (has_res) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            pk_landed(eres2[rr]);
+            const int e = rr * 512 + tid;
+            if (e < n_rs) *reinterpret_cast<uint2 *>(rtab + static_cast<size_t>(e) * 4) = eres2[rr];
+        }
+    }
+    // Fused RMSNorm (rmsnorm.cu / add_residual_and_rmsnorm.cu semantics): h = (x + pre_bias) * gamma * rsqrt(mean((x + pre_bias)^2) + eps).
+    // The register slice is multiplied by gamma only (packed fp16: 4 instructions per fragment); the per-token factor
+    // rsqrt(...) is a ROW scale of the product and is applied to the fp32 sums in the epilogue -- per element that is one
+    // fp16 rounding (of x * gamma) where the unfused sequence has one (of the normalised value), and the 32-row prologue drops
+    // from ~1100 to ~400 VALU instructions (it was 4.5 us of the launch: two waves share a SIMD's issue).
+    float inv_rms[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) inv_rms[t] = 1.f;
+    if (a.gamma) {
+#pragma unroll
+        for (int c = 0; c < GCH; ++c) {
+            pk_landed(graw[c]);
+            pk_landed(praw[c]);
+            const int ch = c * 512 + tid;
+            if (ch < kchunks) {
+                *reinterpret_cast<uint4_t *>(gam + static_cast<size_t>(ch) * 8) = graw[c];
+                *reinterpret_cast<uint4_t *>(gam + a.K + static_cast<size_t>(ch) * 8) = praw[c];
+            }
+        }
+        pk_barrier();
+        if (a.pre_bias) {
+#pragma unroll
+            for (int u = 0; u < XBLK; ++u)
+#pragma unroll
+                for (int s = 0; s < SPB; ++s) {
+                    const half8_t b = *reinterpret_cast<const half8_t *>(gam + a.K + static_cast<size_t>(blkc(u)) * KB + s * 32 + 8 * q);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+                        if (u < cnt && 16 * t + r < a.M) xw[u][s][t] = __builtin_bit_cast(uint4_t, xfrag(xw[u][s][t]) + b);   // fp16 sum, as the unfused kernel stores it
+                }
+        }
+        float ss[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            ss[t] = 0.f;
+#pragma unroll
+            for (int u = 0; u < XBLK; ++u)
+#pragma unroll
+                for (int s = 0; s < SPB; ++s) ss[t] = dot8(xfrag(xw[u][s][t]), xfrag(xw[u][s][t]), ss[t]);
+            ss[t] += __shfl_xor(ss[t], 16, 64);
+            ss[t] += __shfl_xor(ss[t], 32, 64);
+            if (q == 0) stat[(wave * MT + t) * 16 + r] = ss[t];
+        }
+#pragma unroll
+        for (int u = 0; u < XBLK; ++u)
+#pragma unroll
+            for (int s = 0; s < SPB; ++s) {
+                const half8_t g = *reinterpret_cast<const half8_t *>(gam + static_cast<size_t>(blkc(u)) * KB + s * 32 + 8 * q);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) xw[u][s][t] = __builtin_bit_cast(uint4_t, xfrag(xw[u][s][t]) * g);
+            }
+        pk_barrier();
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += stat[(w * MT + t) * 16 + r];
+            inv_rms[t] = rsqrtf(tot / static_cast<float>(a.K) + a.eps);   // of token 16 t + r: this lane's B column AND its D column
+        }
+    }
+    // fp8: the activation rows are quantised per token to the e4m3 grid (scale amax / 448: quantize_rows_fp8's arithmetic)
+    // and packed 8 bytes per fragment; weights and activations go to v_mfma_f32_16x16x32_fp8_fp8 unconverted
+    float xscale[MT];
+    if constexpr (FP8) {
+        pk_barrier();  // stat reuse
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            float amax = 0.f;
+#pragma unroll
+            for (int u = 0; u < XBLK; ++u)
+#pragma unroll
+                for (int s = 0; s < SPB; ++s)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(to_f32(xfrag(xw[u][s][t])[e])));
+            amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+            amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+            if (q == 0) stat[(wave * MT + t) * 16 + r] = amax;
+        }
+        pk_barrier();
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            float amax = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) amax = fmaxf(amax, stat[(w * MT + t) * 16 + r]);
+            const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+            xscale[t] = sc;   // of token 16 t + r: this lane's B column AND its D column
+#pragma unroll
+            for (int u = 0; u < XBLK; ++u)
+#pragma unroll
+                for (int s = 0; s < SPB; ++s) {
+                    // the e4m3 fragment (8 bytes) replaces the fp16 one in the low half of its register quad
+                    const half8_t v = xfrag(xw[u][s][t]);
+                    xw[u][s][t][0] = pack4_e4m3(to_f32(v[0]) / sc, to_f32(v[1]) / sc, to_f32(v[2]) / sc, to_f32(v[3]) / sc);
+                    xw[u][s][t][1] = pack4_e4m3(to_f32(v[4]) / sc, to_f32(v[5]) / sc, to_f32(v[6]) / sc, to_f32(v[7]) / sc);
+                }
+        }
+    }
+    pk_barrier();   // the prologue's statistics / gamma staging alias the reduction slots; tables visible to the epilogue waves
+
+    PK_STAMP(5);
+    // ---- reduction + epilogue of a finished unit ----
+    floatx4 acc[MT];
+    auto publish = [&](const int j, const int parity) {
+        floatx4 *slot = red + static_cast<size_t>(parity) * NW * TPI * MT * 64;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) slot[(wave * TPI * MT + j * MT + t) * 64 + lane] = acc[t];
+    };
+    auto finish = [&](const int it, const int parity) {
+        const floatx4 *slot = red + static_cast<size_t>(parity) * NW * TPI * MT * 64;
+        pk_barrier();  // one barrier per unit: the other parity slot is free for the next unit
+        if (wave < MT) {
+            const int unit = unit_at(it);
+            const int t = wave, m = 16 * t + r;
+            floatx4 v[TPI];
+#pragma unroll
+            for (int j = 0; j < TPI; ++j) {
+                v[j] = slot[(j * MT + t) * 64 + lane];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) v[j] += slot[(w * TPI * MT + j * MT + t) * 64 + lane];
+            }
+            const int n0 = 16 * unit + 4 * q;  // PLAIN / SLAB: output features n0..n0+3; SWIGLU: inter index
+            float xs = t == 0 ? inv_rms[0] : inv_rms[MT - 1];               // MT <= 2: no runtime-indexed register array
+            if constexpr (FP8) xs *= t == 0 ? xscale[0] : xscale[MT - 1];
+            constexpr bool SCALED = WF == PK_I8 || FP8;
+            if constexpr (EPI == PK_EPI_SLAB) {
+                // unscaled partial sums (the weight-row scale is applied by the reduce launch)
+                if (m < a.M && n0 < a.N)
+                    *reinterpret_cast<floatx4 *>(a.slab + (static_cast<size_t>(blockIdx.y) * a.M + m) * a.N + n0) = v[0];
+            } else if constexpr (EPI == PK_EPI_SWIGLU) {
+                const int inter = a.N >> 1;
+                floatx4 sg{1.f, 1.f, 1.f, 1.f}, su{1.f, 1.f, 1.f, 1.f};
+                if constexpr (SCALED) {
+                    sg = *reinterpret_cast<const floatx4 *>(etab + ((it * 2 + 0) * 4 + q) * 4);
+                    su = *reinterpret_cast<const floatx4 *>(etab + ((it * 2 + 1) * 4 + q) * 4);
+                }
+                half4_t y4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gt = v[0][e] * sg[e] * xs, up = v[1][e] * su[e] * xs;
+                    y4[e] = from_f32<half_t>((gt / (1.0f + expf(-gt))) * up);
+                }
+                if (m < a.M && n0 < inter)
+                    *reinterpret_cast<half4_t *>(a.y + (a.y_x32 ? x32_offset(m, n0) : static_cast<size_t>(m) * inter + n0)) = y4;
+            } else {
+                floatx4 sc{1.f, 1.f, 1.f, 1.f};
+                if constexpr (SCALED) sc = *reinterpret_cast<const floatx4 *>(etab + (it * 4 + q) * 4);
+                half4_t r4{0, 0, 0, 0};
+                if (a.residual) r4 = *reinterpret_cast<const half4_t *>(rtab + ((static_cast<size_t>(it) * MT * 16 + m) * 4 + q) * 4);
+                half4_t y4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float f = v[0][e] * sc[e] * xs;
+                    if (a.residual) f += to_f32(r4[e]);
+                    y4[e] = from_f32<half_t>(f);
+                }
+                if (m < a.M && n0 < a.N)
+                    *reinterpret_cast<half4_t *>(a.y + (a.y_x32 ? x32_offset(m, n0) : static_cast<size_t>(m) * a.N + n0)) = y4;
+            }
+        }
+    };
+
+    // ---- main loop over the block stream, software-pipelined by one block: while block k is multiplied the LDS read of
+    //      block k + 1 is in flight and the DMA of block k + D has been issued into the slot block k has just left ----
+    // The kernel is instruction-issue bound before it is HBM bound (PMC: the first form of this loop, with its per-block
+    // index arithmetic and tail tests, spent ~120 instructions per KiB and kept the SIMDs 78 % busy at 3 TB/s), so a tile whose
+    // blocks are all in the steady state (the common case) runs a branch-free body: no tail tests, no per-block ownership
+    // test, two alternating block registers instead of a copy.
+    unsigned sb = 0;         // ring slot (byte offset) of stream element kk
+    int kk = 0;              // stream index of the first block of the current tile
+    const unsigned lds_rd = static_cast<unsigned>(wave * (D * 1024) + lane * 16);
+    auto lds_block = [&](const unsigned slot_bytes) { return *reinterpret_cast<const uint4_t *>(ring_all + lds_rd + slot_bytes); };
+    auto next_slot = [&](const unsigned b) { return b + 1024 == D * 1024 ? 0u : b + 1024; };
+    uint4_t wq[2];           // block kk in wq[0] at every tile start
+    wq[0] = uint4_t{0u, 0u, 0u, 0u};
+    wq[1] = wq[0];
+    if (T > 0) {   // (the prologue's wait retired the first half of the ring fill)
+        wq[0] = lds_block(0);
+        pk_landed(wq[0]);
+    }
+    PK_STAMP(6);
+    auto mma_block = [&](auto u_tag, const uint4_t &w, const half8_t (&af)[(FP8 || WF == PK_F16) ? 1 : SPB]) {
+        constexpr int u = decltype(u_tag)::value;
+        if constexpr (FP8) {
+#pragma unroll
+            for (int s = 0; s < SPB; ++s) {
+                const long wa = static_cast<long>((static_cast<unsigned long>(w[2 * s + 1]) << 32) | w[2 * s]);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const long xa = static_cast<long>((static_cast<unsigned long>(xw[u][s][t][1]) << 32) | xw[u][s][t][0]);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wa, xa, acc[t], 0, 0, 0);
+                }
+            }
+        } else if constexpr (WF == PK_F16) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, w), xfrag(xw[u][0][t]), acc[t], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int s = 0; s < SPB; ++s)
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s], xfrag(xw[u][s][t]), acc[t], 0, 0, 0);
+        }
+    };
+    int parity = 0;
+    for (int i = 0; i < L; ++i) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+        if (cnt == XBLK && kk + XBLK + D <= T) {
+            // steady tile: every block's refill (element + D) and successor (element + 1) exist and are D - 1 deep
+            pk_static_for<XBLK>([&](auto u_tag) {
+                constexpr int u = decltype(u_tag)::value;
+                uint4_t &w = wq[u & 1];
+                pk_landed(w);   // its LDS read (issued a block ago) has returned: the slot may be overwritten by the refill below
+                // successor first: its LDS latency hides behind this block's de-quantisation and MFMAs (element + D is not
+                // issued yet: D - 2 younger DMAs)
+                const unsigned nsb = next_slot(sb);
+                pk_vmwait<D - 2>();
+                wq[(u + 1) & 1] = lds_block(nsb);
+                half8_t af[(FP8 || WF == PK_F16) ? 1 : SPB];
+                if constexpr (!FP8 && WF != PK_F16) {
+#pragma unroll
+                    for (int s = 0; s < SPB; ++s) af[s] = pk_afrag<WF>(w, s);
+                }
+                dma_next(sb);
+                sb = nsb;
+                mma_block(u_tag, w, af);
+            });
+            kk += XBLK;
+        } else {
+            pk_static_for<XBLK>([&](auto u_tag) {
+                constexpr int u = decltype(u_tag)::value;
+                if (u < cnt) {   // wave-uniform
+                    uint4_t w = wq[0];
+                    pk_landed(w);
+                    half8_t af[(FP8 || WF == PK_F16) ? 1 : SPB];
+                    if constexpr (!FP8 && WF != PK_F16) {
+#pragma unroll
+                        for (int s = 0; s < SPB; ++s) af[s] = pk_afrag<WF>(w, s);
+                    }
+                    const int k = kk + u;
+                    if (k + D < T) dma_next(sb);
+                    sb = next_slot(sb);
+                    if (k + 1 < T) {
+                        if (k + 1 + D <= T) pk_vmwait<D - 1>();
+                        else pk_vmwait<0>();
+                        wq[0] = lds_block(sb);
+                    }
+                    mma_block(u_tag, w, af);
+                }
+            });
+            kk += cnt;
+        }
+        if (i == 0) PK_STAMP(7);
+        publish(i % TPI, parity);
+        if (i % TPI == TPI - 1) {
+            finish(i / TPI, parity);
+            parity ^= 1;
+        }
+        if (i == 0) PK_STAMP(8);
+    }
+    PK_STAMP(9);
+}
+
+// ---- packers: row-major weights of the reference layout -> tile-packed image ----
+// One thread per 16-byte chunk of the image.  swiglu != 0: W is a fused gate_up matrix [2I, K]; packed tile 2p holds gate
+// rows [16p, 16p + 16), tile 2p + 1 the matching up rows (I + 16p ...), so a work unit streams one contiguous 2-tile run.
+// Rows past N are zero.
+__device__ __forceinline__ int pk_src_row(int tile, int r, int N, int swiglu) {
+    if (!swiglu) return tile * 16 + r;
+    const int inter = N >> 1, p = tile >> 1;
+    const int i = p * 16 + r;
+    return i < inter ? ((tile & 1) ? inter + i : i) : N;  // N = "no such row"
+}
+
+template <int WF>
+__global__ __launch_bounds__(256) void pk_pack_kernel(const unsigned char *__restrict__ src, uint4_t *__restrict__ dst, int N,
+                                                      int K, int tiles, int swiglu) {
+    using F = PkFmt<WF>;
+    const int nblk = K / F::KB;
+    const size_t total = static_cast<size_t>(tiles) * nblk * 64;
+    for (size_t c = blockIdx.x * 256ull + threadIdx.x; c < total; c += static_cast<size_t>(gridDim.x) * 256) {
+        const int l = static_cast<int>(c & 63), r = l & 15, q = l >> 4;
+        const size_t tb = c >> 6;
+        const int j = static_cast<int>(tb % nblk), tile = static_cast<int>(tb / nblk);
+        const int row = pk_src_row(tile, r, N, swiglu);
+        uint4_t out{0u, 0u, 0u, 0u};
+        if (row < N) {
+            if constexpr (WF == PK_F16) {
+                out = *reinterpret_cast<const uint4_t *>(src + (static_cast<size_t>(row) * K + 32 * j + 8 * q) * 2);
+            } else if constexpr (WF == PK_I8 || WF == PK_FP8) {
+                const unsigned char *p = src + static_cast<size_t>(row) * K + 64 * j + 8 * q;
+                const uint2 a = *reinterpret_cast<const uint2 *>(p), b = *reinterpret_cast<const uint2 *>(p + 32);
+                out = uint4_t{a.x, a.y, b.x, b.y};
+            } else {
+                // source: two nibbles per byte, low nibble = even k.  word s: k = 128 j + 32 s + 8 q + (0..7) = 4 source bytes
+                const unsigned char *p = src + (static_cast<size_t>(row) * K + 128 * j + 8 * q) / 2;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const unsigned int v = *reinterpret_cast<const unsigned int *>(p + 16 * s);  // nibble i of v = k + i
+                    unsigned int o = 0;
+                    // image nibble order (n0,n4,n1,n5,n2,n6,n3,n7) = k (0,1,2,3,4,5,6,7): image nibble pos[i] holds k = i
+                    constexpr int pos[8] = {0, 4, 1, 5, 2, 6, 3, 7};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o |= ((v >> (4 * i)) & 0xFu) << (4 * pos[i]);
+                    out[s] = o;
+                }
+            }
+        }
+        dst[c] = out;
+    }
+}
+
+// int4 group-128 scales [N, K/128] fp16 -> [tiles][nblk][16 rows] (one 32-byte record per block; lane group q reads 8 bytes)
+static __global__ __launch_bounds__(256) void pk_pack_scale4_kernel(const half_t *__restrict__ src, half_t *__restrict__ dst, int N,
+                                                                  int K, int tiles, int swiglu) {
+    const int nblk = K / 128;
+    const size_t total = static_cast<size_t>(tiles) * nblk * 16;
+    for (size_t c = blockIdx.x * 256ull + threadIdx.x; c < total; c += static_cast<size_t>(gridDim.x) * 256) {
+        const int r = static_cast<int>(c & 15);
+        const size_t tb = c >> 4;
+        const int j = static_cast<int>(tb % nblk), tile = static_cast<int>(tb / nblk);
+        const int row = pk_src_row(tile, r, N, swiglu);
+        dst[c] = row < N ? src[static_cast<size_t>(row) * nblk + j] : static_cast<half_t>(0.f);
+    }
+}
+
+// y[m, n] = scale(n, m) * sum_ks slab[ks][m][n] (+ bias[n]) (+ residual[m, n]); 4 columns per thread, every slab load in flight
+static __global__ __launch_bounds__(256) void pk_slab_reduce_kernel(const float *__restrict__ slab, int KS, int M, int N,
+                                                                  const half_t *__restrict__ wscale_h, const float *__restrict__ wscale_f,
+                                                                  const half_t *__restrict__ bias, const half_t *residual, half_t *y,
+                                                                  int res_x32, int y_x32) {
+    const size_t total4 = static_cast<size_t>(M) * N / 4, slab_sz = static_cast<size_t>(M) * N;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total4; i += static_cast<size_t>(gridDim.x) * 256) {
+        const size_t e0 = i * 4;
+        const int n = static_cast<int>(e0 % N);
+        floatx4 v = *reinterpret_cast<const floatx4 *>(slab + e0);
+        for (int k = 1; k < KS; ++k) v += *reinterpret_cast<const floatx4 *>(slab + k * slab_sz + e0);
+        half4_t o, res{0, 0, 0, 0};
+        const int m = static_cast<int>(e0 / N);
+        if (residual) res = *reinterpret_cast<const half4_t *>(residual + (res_x32 ? x32_offset(m, n) : e0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float f = v[e];
+            if (wscale_h) f *= to_f32(wscale_h[n + e]);
+            if (wscale_f) f *= wscale_f[n + e];
+            if (bias) f += to_f32(bias[n + e]);
+            if (residual) f += to_f32(res[e]);
+            o[e] = from_f32<half_t>(f);
+        }
+        *reinterpret_cast<half4_t *>(y + (y_x32 ? x32_offset(m, n) : e0)) = o;
+    }
+}
+
+// row-major [M, K] fp16 <-> x32 (to_x32 != 0: rows >= M of the image are zero-filled); one thread per 8 halves
+static __global__ __launch_bounds__(256) void x32_convert_kernel(const half_t *__restrict__ src, half_t *__restrict__ dst, int M, int K,
+                                                              int to_x32) {
+    const size_t total = static_cast<size_t>(32) * (K >> 3);
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * 256) {
+        const int m = static_cast<int>(i / (K >> 3)), k = static_cast<int>(i % (K >> 3)) * 8;
+        if (to_x32) {
+            uint4_t v{0u, 0u, 0u, 0u};
+            if (m < M) v = *reinterpret_cast<const uint4_t *>(src + static_cast<size_t>(m) * K + k);
+            *reinterpret_cast<uint4_t *>(dst + x32_offset(m, k)) = v;
+        } else if (m < M) {
+            *reinterpret_cast<uint4_t *>(dst + static_cast<size_t>(m) * K + k) = *reinterpret_cast<const uint4_t *>(src + x32_offset(m, k));
+        }
+    }
+}
+
+}  // namespace llmie

@@ -66,3 +66,20 @@ def test_missing_library_raises(llmie, monkeypatch):
     monkeypatch.setattr(llmie, "LIB_PATH", "/nonexistent/libllmie.so")
     with pytest.raises(llmie.LlmieError):
         llmie.lib()
+
+
+def test_packed_kernels_do_not_spill():
+    """pk_mfma_kernel issues its global loads from inline asm with hand-counted waits: a spilled register there could be one whose
+    load is still in flight, so no instantiation may use scratch (checked on the built code object, no GPU needed)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("ckr", os.path.join(root, "tools", "check_kernel_resources.py"))
+    ckr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ckr)
+    obj = os.path.join(root, "llm-inference-engine_amd", "csrc", "_obj", "pk_linear.hip.o")
+    ks = [k for k in ckr.kernel_metadata(obj) if "pk_mfma_kernel" in k["name"]]
+    assert len(ks) >= 24
+    bad = [k for k in ks if k["vgpr_spill"] or k["scratch"]]
+    assert not bad, bad
+    assert all(k["vgpr"] <= 256 for k in ks)
