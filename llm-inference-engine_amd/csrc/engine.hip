@@ -32,6 +32,17 @@ struct llmie_decoder {
     void *fp8_ws;        // LLMIE_W_FP8 engines: activation quantisation + split-K scratch of llmie_linear_fp8
     size_t fp8_ws_bytes;
     int32_t *tickets;    // [max_batch, kv_head_num] arrival counters of the in-launch attention merge (zero between launches)
+    // packed-weight batch path (gemv_max < batch <= 32): tile-packed images of the four matrices of every layer (built once at
+    // create time into the caller's workspace: the MI355X's 288 GB buy a second, stream-friendly copy of the weights), the
+    // activations between the packed kernels in the x32 layout, and the split-K slabs of the down projection
+    struct PackedLayer {
+        const unsigned char *qkv, *o, *gate_up, *down;
+    };
+    std::vector<PackedLayer> packed;
+    int pk_wf = 0;                    // PKF_* of the engine's weight format, 0 = no packed path
+    half_t *hx = nullptr, *actx = nullptr;   // x32 images: residual stream [32, H], SwiGLU output [32, I]
+    float *pk_slab = nullptr;
+    size_t pk_slab_floats = 0;
     // paged KV cache of the current llmie_decoder_forward_paged call (null: dense caches)
     const int32_t *page_table = nullptr;
     int max_pages = 0, num_pages = 0;
@@ -95,7 +106,49 @@ struct Carve {
     }
 };
 
-static size_t carve(const llmie_decoder_config *c, size_t *offs /*[10]*/) {
+// weight format / shapes the packed batch path covers; max rows it will be asked for
+static int packed_wf(const llmie_decoder_config *c) {
+    if (c->dtype != LLMIE_F16) return 0;
+    const int wf = c->wfmt == LLMIE_W_F16 ? PKF_F16 : (c->wfmt == LLMIE_W_INT8 ? PKF_I8 : (c->wfmt == LLMIE_W_FP8 ? PKF_FP8 : 0));
+    // batches up to the GEMV crossover never take the packed path: no second copy of the weights for such engines
+    const int gemv_max = c->wfmt == LLMIE_W_FP8 ? 3 : 4;
+    if (!wf || c->max_batch <= gemv_max) return 0;
+    const int H = c->head_num * c->head_size, QKV = (c->head_num + 2 * c->kv_head_num) * c->head_size, I = c->inter_size;
+    const int m = c->max_batch < 32 ? c->max_batch : 32;
+    const int mm = wf == PKF_FP8 && m > 16 ? 16 : m;
+    if (H % 32 || I % 32) return 0;
+    if (!pk_eligible(wf, mm, H, QKV, PKE_PLAIN) || !pk_eligible(wf, mm, H, H, PKE_PLAIN) || !pk_eligible(wf, mm, H, 2 * I, PKE_SWIGLU) ||
+        !pk_eligible(wf, mm, I, H, PKE_PLAIN))
+        return 0;
+    if (wf == PKF_FP8 && pk_slab_floats(wf, mm, I, H)) return 0;   // per-token activation scales: the down projection must not split K
+    return wf;
+}
+struct PackedCarve {
+    size_t per_layer[4], layer_bytes, hx, actx, slab, total;
+};
+static PackedCarve packed_carve(const llmie_decoder_config *c, int wf) {
+    PackedCarve p{};
+    if (!wf) return p;
+    const int H = c->head_num * c->head_size, QKV = (c->head_num + 2 * c->kv_head_num) * c->head_size, I = c->inter_size;
+    p.per_layer[0] = align_up(pk_packed_bytes(wf, QKV, H, 0));
+    p.per_layer[1] = align_up(pk_packed_bytes(wf, H, H, 0));
+    p.per_layer[2] = align_up(pk_packed_bytes(wf, 2 * I, H, 1));
+    p.per_layer[3] = align_up(pk_packed_bytes(wf, H, I, 0));
+    p.layer_bytes = p.per_layer[0] + p.per_layer[1] + p.per_layer[2] + p.per_layer[3];
+    p.hx = align_up(static_cast<size_t>(H) * 64);
+    p.actx = align_up(static_cast<size_t>(I) * 64);
+    const int m = c->max_batch < 32 ? c->max_batch : 32;
+    size_t sl = 0;
+    for (int mm = 1; mm <= m; ++mm) {
+        const size_t f = pk_slab_floats(wf, mm, I, H);
+        sl = f > sl ? f : sl;
+    }
+    p.slab = align_up(sl * sizeof(float) + 16);
+    p.total = p.layer_bytes * c->num_layers + p.hx + p.actx + p.slab;
+    return p;
+}
+
+static size_t carve(const llmie_decoder_config *c, size_t *offs /*[11]*/) {
     const size_t e = c->dtype == LLMIE_F16 ? 2 : 4;
     const size_t B = c->max_batch, H = static_cast<size_t>(c->head_num) * c->head_size;
     const size_t QKV = static_cast<size_t>(c->head_num + 2 * c->kv_head_num) * c->head_size;
@@ -113,12 +166,13 @@ static size_t carve(const llmie_decoder_config *c, size_t *offs /*[10]*/) {
     const int kmax = c->inter_size > static_cast<int>(H) ? c->inter_size : static_cast<int>(H);
     // fp8: three activation-quantisation units (normed input, attention output, SwiGLU output), see decoder_forward
     offs[9] = k.take(c->wfmt == LLMIE_W_FP8 ? 3 * llmie_linear_fp8_workspace_bytes(c->max_batch, kmax) : 256);
+    offs[10] = k.take(packed_carve(c, packed_wf(c)).total + 256);   // packed weight images + x32 activations + slabs
     return k.off;
 }
 
 extern "C" size_t llmie_decoder_workspace_bytes(const llmie_decoder_config *cfg) {
     if (!config_ok(cfg)) return 0;
-    size_t offs[10];
+    size_t offs[11];
     return carve(cfg, offs);
 }
 
@@ -132,7 +186,7 @@ extern "C" llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg, 
         set_error("decoder_create: NULL layers/workspace");
         return nullptr;
     }
-    size_t offs[10];
+    size_t offs[11];
     const size_t need = carve(cfg, offs);
     if (workspace_bytes < need) {
         set_error("decoder_create: workspace too small (%zu < %zu)", workspace_bytes, need);
@@ -177,6 +231,36 @@ extern "C" llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg, 
     {
         const int kmax = cfg->inter_size > d->H ? cfg->inter_size : d->H;
         d->fp8_ws_bytes = cfg->wfmt == LLMIE_W_FP8 ? llmie_linear_fp8_workspace_bytes(cfg->max_batch, kmax) : 0;
+    }
+    d->pk_wf = packed_wf(cfg);
+    if (d->pk_wf) {
+        // one-time re-tiling of every matrix into the stream-friendly image (null stream, synchronous: create is not on the
+        // compute path); the row-major originals stay in use for batch <= gemv_max (GEMV) and for prefill
+        const PackedCarve pc = packed_carve(cfg, d->pk_wf);
+        unsigned char *pb = reinterpret_cast<unsigned char *>(base + offs[10]);
+        const int H = d->H, QKV = d->QKV, I = d->I;
+        d->packed.resize(cfg->num_layers);
+        int prc = LLMIE_OK;
+        for (int l = 0; l < cfg->num_layers && prc == LLMIE_OK; ++l) {
+            unsigned char *q = pb + static_cast<size_t>(l) * pc.layer_bytes;
+            unsigned char *po = q + pc.per_layer[0], *pg = po + pc.per_layer[1], *pd = pg + pc.per_layer[2];
+            const llmie_layer_weights &w = layers[l];
+            prc = pk_pack(d->pk_wf, w.qkv.data, nullptr, q, nullptr, QKV, H, 0, nullptr);
+            if (!prc) prc = pk_pack(d->pk_wf, w.o.data, nullptr, po, nullptr, H, H, 0, nullptr);
+            if (!prc) prc = pk_pack(d->pk_wf, w.gate_up.data, nullptr, pg, nullptr, 2 * I, H, 1, nullptr);
+            if (!prc) prc = pk_pack(d->pk_wf, w.down.data, nullptr, pd, nullptr, H, I, 0, nullptr);
+            d->packed[l] = llmie_decoder::PackedLayer{q, po, pg, pd};
+        }
+        unsigned char *tail = pb + pc.layer_bytes * cfg->num_layers;
+        d->hx = reinterpret_cast<half_t *>(tail);
+        d->actx = reinterpret_cast<half_t *>(tail + pc.hx);
+        d->pk_slab = reinterpret_cast<float *>(tail + pc.hx + pc.actx);
+        d->pk_slab_floats = (pc.slab - 16) / sizeof(float);
+        if (prc != LLMIE_OK || hipMemset(tail, 0, pc.hx + pc.actx) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            set_error("decoder_create: packing the weights for the batch path failed");
+            delete d;
+            return nullptr;
+        }
     }
     if (hipMemset(d->tickets, 0, static_cast<size_t>(cfg->max_batch) * cfg->kv_head_num * sizeof(int32_t)) != hipSuccess) {
         set_error("decoder_create: ticket memset failed");
@@ -386,6 +470,44 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
             TIMED(LLMIE_OP_O_GEMM, lin(dec->mha, w.o, h, H, H, EPI_NONE_, h, nullptr, nullptr));
             TIMED(LLMIE_OP_GATE_UP_SWIGLU, lin(h, w.gate_up, dec->act, H, 2 * I, EPI_SWIGLU_, nullptr, w.ffn_norm_gamma, w.o.bias));
             TIMED(LLMIE_OP_DOWN_GEMM, lin(dec->act, w.down, h, I, H, EPI_NONE_, h, nullptr, nullptr));
+        }
+        return LLMIE_OK;
+    }
+
+    // ---- packed-weight batch path (gemv_max < batch <= 32; fp16 / int8 weights, fp8 up to 16 rows): 6 launches per layer, no
+    // fp32 slab round trip except the down projection's K split --
+    //   qkv  = rmsnorm(h) * g1 . Wqkv^T            norm in the kernel's prologue (per-token factor in its epilogue), fp16 qkv rows
+    //   mha  = attention(rope(q), rope(k) -> cache, v)
+    //   hx   = h + mha . Wo^T                       residual epilogue, x32 image of the residual stream
+    //   actx = swiglu(rmsnorm(hx + o.bias) * g2 . Wgu^T)
+    //   hx  += actx . Wd^T                          K split over workgroups (K = inter_size) + one reduce launch
+    // Same math as self_decoder.cpp:69-119.  Weights come from the tile-packed images built at create time.
+    static const int packed_off = getenv("LLMIE_NO_PACKED_BATCH") ? 1 : 0;
+    const int pk_rows_max = fp8 ? 16 : 32;
+    if (!packed_off && !fused_off && dec->pk_wf && batch > gemv_max && batch <= pk_rows_max && hs_ok && rep_ok) {
+        hipStream_t st = as_stream(stream);
+        const int wf = dec->pk_wf;
+        half_t *hh = static_cast<half_t *>(h);
+        half_t *mha = reinterpret_cast<half_t *>(dec->mha), *qkvb = reinterpret_cast<half_t *>(dec->qkv);
+        for (int l = 0; l < c.num_layers; ++l) {
+            const llmie_layer_weights &w = dec->layers[l];
+            const llmie_decoder::PackedLayer &pw = dec->packed[l];
+            const bool first = l == 0, last = l + 1 == c.num_layers;
+            // layer 0 reads the caller's row-major hidden state; from its output projection on the residual stream lives in hx
+            TIMED(LLMIE_OP_QKV_GEMM, pk_linear(wf, first ? hh : dec->hx, pw.qkv, w.qkv.scale, qkvb, batch, H, QKV, PKE_PLAIN, first ? 0 : PKX_X,
+                                               nullptr, static_cast<const half_t *>(w.attn_norm_gamma), nullptr, c.rms_eps, nullptr, 0, st));
+            TIMED(LLMIE_OP_MHA, decoder_mha_rope(dec->qkv, w.qkv.bias, k_cache, v_cache, dec->mha, l, batch, c.head_num, c.kv_head_num,
+                                                 c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws, dec->attn_ws_bytes,
+                                                 dec->rope_table, c.rotary_dim, nullptr, dt, st, nullptr, nullptr, kv8, k_scale, v_scale,
+                                                 dec->page_table, dec->max_pages, dec->num_pages));
+            TIMED(LLMIE_OP_O_GEMM, pk_linear(wf, mha, pw.o, w.o.scale, dec->hx, batch, H, H, PKE_PLAIN, PKX_Y | (first ? 0 : PKX_RES),
+                                             first ? hh : dec->hx, nullptr, nullptr, 0.f, nullptr, 0, st));
+            TIMED(LLMIE_OP_GATE_UP_SWIGLU, pk_linear(wf, dec->hx, pw.gate_up, w.gate_up.scale, dec->actx, batch, H, 2 * I, PKE_SWIGLU, PKX_X | PKX_Y,
+                                                     nullptr, static_cast<const half_t *>(w.ffn_norm_gamma), static_cast<const half_t *>(w.o.bias),
+                                                     c.rms_eps, nullptr, 0, st));
+            TIMED(LLMIE_OP_DOWN_GEMM, pk_linear(wf, dec->actx, pw.down, w.down.scale, last ? hh : dec->hx, batch, I, H, PKE_PLAIN,
+                                                PKX_X | PKX_RES | (last ? 0 : PKX_Y), dec->hx, nullptr, nullptr, 0.f, dec->pk_slab,
+                                                dec->pk_slab_floats, st));
         }
         return LLMIE_OK;
     }

@@ -60,6 +60,19 @@ int linear_wq(int wbits, const half_t *x, const void *wq, const half_t *scale, h
               int epi, const half_t *bias, const half_t *residual, const half_t *gamma, const half_t *pre_bias, float eps,
               hipStream_t st);
 
+// ---- packed-weight batch-decode projections (pk_gemm.cuh / pk_linear.hip): 1 <= M <= 32 rows on tile-packed weight images ----
+enum : int { PKF_F16 = 16, PKF_I8 = 8, PKF_I4 = 4, PKF_FP8 = 108 };                 // = PK_F16 ... of pk_gemm.cuh
+enum : int { PKE_PLAIN = 0, PKE_SWIGLU = 1 };
+enum : int { PKX_X = 1, PKX_Y = 2, PKX_RES = 4 };                                    // operands in the x32 activation layout
+size_t pk_packed_bytes(int wf, int N, int K, int swiglu);
+int pk_pack(int wf, const void *src, const void *src_scale, void *dst, void *dst_scale, int N, int K, int swiglu, hipStream_t st);
+bool pk_eligible(int wf, int M, int K, int N, int epi);
+size_t pk_slab_floats(int wf, int M, int K, int N);
+int pk_linear(int wf, const half_t *x, const void *Wp, const void *scale, half_t *y, int M, int K, int N, int epi, int x32_flags,
+              const half_t *residual, const half_t *gamma, const half_t *pre_bias, float eps, float *slab_ws, size_t slab_ws_floats,
+              hipStream_t st);
+int x32_convert(const half_t *src, half_t *dst, int M, int K, int to_x32, hipStream_t st);
+
 // decode attention with optional RoPE (rope may be null) fused in front (rope = [max_pos][head_size/2] (cos,sin) table); attention_decode.hip
 int decoder_mha_rope(const void *qkv, const void *qkv_bias, void *k_cache, void *v_cache, void *out, int layer, int batch,
                      int head_num, int kv_head_num, int head_size, int max_seq_len, int step, const int32_t *step_dev,

@@ -68,7 +68,9 @@ static bool pk_plan(int wf, int K, int units, bool may_split, PkPlan *p) {
     const int ks_min = (nblk + cap - 1) / cap;
     if (!may_split && ks_min > 1) return false;
     int best_cost = 1 << 30;
-    for (int ks = ks_min; ks <= (may_split ? 8 : 1) && ks <= nblk; ++ks) {
+    // K is split over workgroups only where the register-resident slice forces it (then the best split >= the minimum is
+    // taken); a shape that fits unsplit never needs a slab workspace
+    for (int ks = ks_min; ks <= (may_split && ks_min > 1 ? 8 : 1) && ks <= nblk; ++ks) {
         const int bps = (nblk + ks - 1) / ks;
         if ((nblk + bps - 1) / bps != ks) continue;  // every slice non-empty
         const int gx = units < CUS / ks ? units : CUS / ks;

@@ -63,6 +63,10 @@ CASES = [
     # more than one 16-row MFMA tile, a context spanning several attention chunks; bs 130 takes the unfused path
     ("7Bgeom_fp16_bs20_L2", torch.float16, 32, 32, 128, 11008, 2, 20, 64, [33], False),
     ("gqa_fp16_bs40_L3_bias", torch.float16, 16, 4, 128, 1024, 3, 40, 320, [300], True),
+    # packed-weight batch path (4 < batch <= 32): first / middle / last layer forms (row-major in, x32 between, row-major out),
+    # one and two 16-row tiles, o.bias as the FFN norm's pre-bias, GQA
+    ("7Bgeom_fp16_bs7_L3_bias", torch.float16, 32, 32, 128, 11008, 3, 7, 64, [33], True),
+    ("gqa_fp16_bs32_L3_bias", torch.float16, 16, 4, 128, 1024, 3, 32, 320, [300], True),
     ("mha64_fp16_bs128_L2_bias", torch.float16, 8, 8, 64, 768, 2, 128, 48, [17], True),
     ("mha64_fp16_bs130_L2_bias", torch.float16, 8, 8, 64, 768, 2, 130, 48, [17], True),
 ]

@@ -96,7 +96,7 @@ def test_linear_w8_fused_bias_residual(llmie):
     assert np.abs(y.float().cpu().numpy() - exp).max() <= 8e-3
 
 
-@pytest.mark.parametrize("fmt,bs", [("int8", 1), ("int8", 4), ("int8", 20), ("int8", 72), ("int4", 1), ("int4", 2), ("int4", 6), ("int4", 19), ("int4", 40), ("int4", 70)])
+@pytest.mark.parametrize("fmt,bs", [("int8", 1), ("int8", 4), ("int8", 9), ("int8", 20), ("int8", 32), ("int8", 72), ("int4", 1), ("int4", 2), ("int4", 6), ("int4", 19), ("int4", 40), ("int4", 70)])
 def test_quantised_decoder_matches_oracle_on_dequantised_weights(llmie, fmt, bs):
     rng = np.random.default_rng(35)
     nh, hs, I, L, max_seq, step, group = 32, 128, 11008, 1, 96, 40, 128
