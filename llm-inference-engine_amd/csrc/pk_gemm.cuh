@@ -165,39 +165,46 @@ __device__ unsigned long long pk_stamp_buf[256 * 8 * 16];
 #endif
 
 constexpr int PK_MAX_UNITS = 16;   // work units per workgroup whose epilogue operands are pre-staged in LDS
-__host__ __device__ constexpr int pk_ring_depth(int epi) { return epi == PK_EPI_SWIGLU ? 11 : 12; }
+__host__ __device__ constexpr int pk_ring_depth(int) { return 12; }
 // LDS carve (bytes), shared by the kernel and the host launcher
 struct PkLds {
     int red, ring, etab, rtab, total;
 };
-__host__ __device__ constexpr PkLds pk_lds(int mt, int epi, int norm_k /* K if a norm is fused, else 0 */, bool resid) {
+__host__ __device__ constexpr PkLds pk_lds(int mt, int epi, int norm_halves /* staged gamma (+ pre_bias) halves: K or 2 K, 0 = no norm */, bool resid) {
     const int tpi = epi == PK_EPI_SWIGLU ? 2 : 1;
-    int red = 2 * 8 * tpi * mt * 1024;                     // [2 parities][8 waves][tpi * mt tiles][64 lanes] floatx4
-    const int stage = 8 * mt * 16 * 4 + 4 * norm_k;        // prologue only, aliases `red`: norm / amax statistics + gamma + pre_bias
-    if (stage > red) red = stage;
-    if (red < 8 * 4096) red = 8 * 4096;                    // prologue only, aliases `red`: one 4 KiB transposition patch per wave
+    const int npar = tpi == 1 ? 2 : 1;
+    int red = npar * 8 * tpi * mt * 1024;                  // [parities][8 waves][tpi * mt tiles][64 lanes] floatx4
+    if (red < 8 * 4096) red = 8 * 4096;                    // prologue only, aliases `red`: one 4 KiB transposition patch per wave (row-major x)
     const int ring = 8 * pk_ring_depth(epi) * 1024;
     const int etab = epi == PK_EPI_SLAB ? 0 : PK_MAX_UNITS * tpi * 16 * 4;   // row scales (fp32) of every unit of the workgroup
     const int rtab = resid ? PK_MAX_UNITS * mt * 16 * 16 * 2 : 0;            // residual pieces [unit][mt * 16 rows][16] fp16
-    return PkLds{red, ring, etab, rtab, red + ring + etab + rtab};
+    const int stat = 2 * 8 * mt * 16 * 4 + 2 * norm_halves;   // norm / amax statistics, gamma (+ pre_bias) staging
+    return PkLds{red, ring, etab, rtab, red + ring + etab + rtab + stat};
 }
 
-template <int MT, int WF, int EPI, bool XL /* x is in the x32 layout */>
+// XM (activation layout, a compile-time fact of the launch): 0 = row-major x; 1 = x32 image
+template <int MT, int WF, int EPI, int XM>
 __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
+    constexpr bool XL = XM != 0;
     using F = PkFmt<WF>;
     constexpr int NW = 8, KB = F::KB, SPB = F::SPB, XBLK = F::XBLK;
-    constexpr bool FP8 = WF == PK_FP8, I4 = WF == PK_I4;
-    constexpr int TPI = EPI == PK_EPI_SWIGLU ? 2 : 1;   // tiles per work unit
+    constexpr bool FP8 = WF == PK_FP8;
+    constexpr bool SCALED = WF == PK_I8 || FP8;          // per-row weight scales applied in the epilogue
+    constexpr int TPI = EPI == PK_EPI_SWIGLU ? 2 : 1;    // tiles per work unit
+    constexpr int NPAR = TPI == 1 ? 2 : 1;               // reduction-slot parities (SwiGLU: one slot set + a second barrier per unit)
     constexpr int D = pk_ring_depth(EPI);
+    constexpr int XPB = SPB * MT;                        // activation fragments (= loads) per block
+    static_assert(XBLK % 2 == 0, "two alternating block registers per tile");
     typedef __attribute__((address_space(3))) void *lptr_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char pk_smem[];
-    const PkLds lay = pk_lds(MT, EPI, a.gamma ? a.K : 0, EPI == PK_EPI_PLAIN && a.residual != nullptr);
-    floatx4 *red = reinterpret_cast<floatx4 *>(pk_smem);                 // [2][NW][TPI * MT][64]
-    float *stat = reinterpret_cast<float *>(pk_smem);                     // prologue only (aliases red): [NW][MT][16]
-    half_t *gam = reinterpret_cast<half_t *>(pk_smem + NW * MT * 16 * 4); // prologue only: gamma [K], pre_bias [K]
+    const bool has_res = EPI == PK_EPI_PLAIN && a.residual != nullptr;
+    const PkLds lay = pk_lds(MT, EPI, a.gamma ? (a.pre_bias ? 2 * a.K : a.K) : 0, has_res);
+    floatx4 *red = reinterpret_cast<floatx4 *>(pk_smem);                                  // [NPAR][NW][TPI * MT][64]
     unsigned char *ring_all = pk_smem + lay.red;
-    float *etab = reinterpret_cast<float *>(pk_smem + lay.red + lay.ring);           // [units][TPI][16]
-    half_t *rtab = reinterpret_cast<half_t *>(pk_smem + lay.red + lay.ring + lay.etab);  // [units][MT * 16][16]
+    float *etab = reinterpret_cast<float *>(pk_smem + lay.red + lay.ring);               // [units][TPI][16] row scales
+    half_t *rtab = reinterpret_cast<half_t *>(pk_smem + lay.red + lay.ring + lay.etab);  // [units][MT * 16][16] residual pieces
+    float *stat = reinterpret_cast<float *>(pk_smem + lay.red + lay.ring + lay.etab + lay.rtab);   // [2][NW][MT][16] sum of squares | amax
+    half_t *gam = reinterpret_cast<half_t *>(stat + 2 * NW * MT * 16);                   // gamma [K], pre_bias [K] (fused norm only)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: K range, block addresses stay scalar
@@ -227,9 +234,8 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
     const long step_unit = static_cast<long>(static_cast<size_t>(gridDim.x) * TPI - (TPI - 1)) * static_cast<long>(tile_bytes) - static_cast<long>(cnt) * 1024;
     const unsigned char *src = a.Wp + (static_cast<size_t>(unit_at(0)) * TPI * a.nblk + blk0) * 1024;
     int ri = 0, ru = 0;   // (tile, block) of the next stream element to fetch
-    // fetch the next stream element into ring slot byte offset `sb` and advance the source
-    auto dma_next = [&](const unsigned sb) {
-        pk_dma16_nt(woff, src, ring_lds + sb);
+    auto dma_next = [&](const unsigned slot_bytes) {
+        pk_dma16_nt(woff, src, ring_lds + slot_bytes);
         src += 1024;
         if (++ru == cnt) {
             ru = 0;
@@ -239,178 +245,120 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
     };
 
     PK_STAMP(0);
-    // ---- first half of the ring fill goes out before anything else: its HBM latency runs under the issue of the activation
-    //      loads (256 KiB per CU at the L1's 64 bytes per clock = 1.7 us by itself); the second half follows them, so that the
-    //      one prologue wait below (loads retire in order) leaves half a ring in flight for the start of the loop ----
-    constexpr int DH = D / 2;
-    for (int k = 0; k < DH && k < T; ++k) dma_next(k * 1024);
-    // ---- prologue loads (all asm, one wait): activation slice, gamma / pre_bias, epilogue operands ----
-    // Activation slice of this wave = rows [0, 16 MT) x its XBLK blocks.  Fragment-shaped global loads (16 rows x 64 bytes per
-    // wave instruction) are TA-bound (~90 cycles each: this prologue took ~10 us that way), so the slice is fetched in
-    // row-contiguous pieces -- one instruction = 4 rows x 256 bytes (two blocks' worth of k) -- into the SAME registers that
-    // will hold the B fragments, and turned into fragments 4 KiB at a time through a private LDS patch after the wait.
-    //   piece (t, c, i): rows 16 t + 4 i + (lane >> 4), bytes [256 c + 16 (lane & 15), +16) of the slice row   (c = block pair)
-    //   fragment (u, s, t): lane (r, q) <- row 16 t + r, bytes [128 u + 64 s + 16 q, +16)                        (u = 2 c + uu)
-    static_assert(KB * 2 == 128 || WF == PK_F16 || WF == PK_I4, "block = 128 activation bytes per row for the 8-bit formats");
-    constexpr int XB = KB * 2;                 // activation bytes per block and row (fp16 x): 64 / 128 / 256
-    constexpr int PAIRB = 256;                 // bytes of one row piece
-    constexpr int NPAIR = XBLK * XB / PAIRB;   // row pieces per row: 16 * 64 / 256 = 4 (fp16 weights), 8 * 128 / 256 = 4, 4 * 256 / 256 = 4
-    static_assert(NPAIR * 4 == XBLK * SPB, "register count of pieces == fragments");
-    uint4_t xw[XBLK][SPB][MT];
-    auto piece = [&](int t, int c, int i) -> uint4_t & {   // the register that receives piece (t, c, i): any bijection onto xw
-        const int f = c * 4 + i;                            // 0 .. XBLK * SPB - 1
-        return xw[f / SPB][f % SPB][t];
-    };
-    if constexpr (XL) {
-        // fragment (u, s, t) = the KiB at ((kstep * 2 + t) * 1 KiB), kstep = block * SPB + s: one contiguous load each.
-        // Every workgroup of the launch reads the SAME activation image; started in lock step they all sit on the same few L2
-        // channels at any moment (measured: 256 KiB per CU took 3.9 us, half the L2's rate), so the workgroups that share an
-        // XCD (blockIdx / 8 = consecutive CUs of one XCD under round-robin placement -- speed only) start a quarter of the way
-        // around from each other.
-        auto issue_from = [&](auto q0_tag) {
-            constexpr int U0 = decltype(q0_tag)::value * (XBLK / 4);
-            pk_static_for<XBLK>([&](auto v_tag) {
-                constexpr int u = (decltype(v_tag)::value + U0) % XBLK;
-#pragma unroll
-                for (int s2 = 0; s2 < SPB; ++s2)
-#pragma unroll
-                    for (int t = 0; t < MT; ++t)
-                        pk_gload16_s(xw[u][s2][t], woff, reinterpret_cast<const unsigned char *>(a.x) + (static_cast<size_t>(blkc(u)) * SPB + s2) * 2048 + t * 1024);
-            });
-        };
-        switch ((blockIdx.x >> 3) & 3) {
-            case 0: issue_from(std::integral_constant<int, 0>{}); break;
-            case 1: issue_from(std::integral_constant<int, 1>{}); break;
-            case 2: issue_from(std::integral_constant<int, 2>{}); break;
-            default: issue_from(std::integral_constant<int, 3>{}); break;
-        }
-    } else {
-        const size_t slice_bytes = static_cast<size_t>(a.K) * 2;
-        // first byte of the slice inside a row, clamped so that every piece stays inside the row (blocks the wave does not own
-        // are zeroed below)
-        const size_t sb0 = min(static_cast<size_t>(blk0) * XB, slice_bytes - static_cast<size_t>(XBLK) * XB);
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned voff = static_cast<unsigned>(min(16 * t + 4 * i + (lane >> 4), a.M - 1)) * static_cast<unsigned>(slice_bytes) + 16 * (lane & 15);
-#pragma unroll
-                for (int c = 0; c < NPAIR; ++c)
-                    pk_gload16_s(piece(t, c, i), voff, reinterpret_cast<const unsigned char *>(a.x) + sb0 + c * PAIRB);
-            }
-    }
+    // ================= issue phase: every asm load of the kernel except the ring refills, oldest first =================
+    // Loads RETURN in issue order (one in-order path per CU; vmcnt counts them that way), and every 1 KiB wave-load takes the
+    // CU's address path 16 cycles (64 B/clk): what a launch pays before its first MFMA is the bytes it requests up front --
+    // activation slice 256 KiB per CU at 32 rows, ring fill 96 KiB, small operands -- plus one cold HBM latency.  Order:
+    // (1) the small operands (needed first; only the ones this launch has), (2) the ring fill, so the HBM stream starts at
+    // once, (3) the activation slice (L2 / MALL), which then arrives right behind the ring.  [Measured alternatives, batch 32,
+    // in the decode step: activations in front of the ring fill: equal or 0.5-1.5 us/launch slower (HBM idles until they are
+    // through); the first tiles streamed block-major so that the activations spread over 2-4 tiles of HBM time: equal (what
+    // the spread gains, the back-to-back reductions of those tiles at the end of the pass cost).]
+    // (1) small operands: gamma / pre_bias chunks for the LDS staging, and the epilogue operands of every unit of this
+    //     workgroup (row scales, residual pieces) -> LDS tables, so that the loop contains no VGPR-returning global load at all.
+    //     The wait for them counts the YOUNGER loads only, so their own number may differ from launch to launch.
     constexpr int GCH = PK_NORM_MAX_K / 4096;   // gamma / pre_bias: 16-byte chunks per thread
+    constexpr bool HAS_ST = SCALED && EPI != PK_EPI_SLAB, HAS_RT = EPI == PK_EPI_PLAIN;
     uint4_t graw[GCH], praw[GCH];
     const int kchunks = a.K >> 3;
-    if (a.gamma) {
+    if (a.gamma) {   // kernel-uniform
 #pragma unroll
         for (int c = 0; c < GCH; ++c) {
-            const unsigned goff = static_cast<unsigned>(min(c * 512 + tid, kchunks - 1)) * 16;
-            pk_gload16_s(graw[c], goff, a.gamma);
-            pk_gload16_s(praw[c], goff, a.pre_bias ? a.pre_bias : a.gamma);
+            if (c * 512 < kchunks) {   // K <= 4096: one chunk per thread
+                const unsigned goff = static_cast<unsigned>(min(c * 512 + tid, kchunks - 1)) * 16;
+                pk_gload16_s(graw[c], goff, a.gamma);
+                if (a.pre_bias) pk_gload16_s(praw[c], goff, a.pre_bias);
+            }
         }
     }
-    // epilogue operands of every unit of this workgroup -> LDS tables (the loop then needs no VGPR-returning global load):
-    // thread e of the first `iters * TPI * 4` threads fetches 4 row scales; `iters * MT * 16 * 4`... threads 4 residual halves
+    const int n_sc = HAS_ST ? iters * TPI * 4 : 0;                 // items of 4 row scales
+    const int n_rs = has_res ? iters * MT * 16 * 4 : 0;            // items of 4 residual halves
     uint2 escale{0u, 0u};
-    const int n_sc = (EPI == PK_EPI_SLAB || (WF != PK_I8 && !FP8)) ? 0 : iters * TPI * 4;   // items of 4 scales
-    const bool has_res = EPI == PK_EPI_PLAIN && a.residual != nullptr;
-    const int n_rs = has_res ? iters * MT * 16 * 4 : 0;                                         // items of 4 halves
     uint4_t escale4{0u, 0u, 0u, 0u};
-    if (tid < n_sc) {
-        const int it = tid / (TPI * 4), j = (tid / 4) % TPI, c = tid & 3;
-        int n = 16 * unit_at(it) + 4 * c;                       // PLAIN: feature; SWIGLU: inter index (+ inter for the up tile)
+    if (HAS_ST && tid < n_sc) {
+        const int e = tid;
+        const int it = e / (TPI * 4), j = (e / 4) % TPI, c = e & 3;
+        int n = 16 * unit_at(it) + 4 * c;                          // PLAIN: feature; SWIGLU: inter index (+ inter for the up tile)
         if constexpr (EPI == PK_EPI_SWIGLU) n = min(n, (a.N >> 1) - 4) + j * (a.N >> 1);
         else n = min(n, a.N - 4);
         if constexpr (FP8) pk_gload16(escale4, reinterpret_cast<const float *>(a.scale) + n);
         else pk_gload8(escale, reinterpret_cast<const half_t *>(a.scale) + n);
     }
-    uint2 eres2[4];   // PK_MAX_UNITS * MT * 64 <= 2048 items = 4 rounds of the 512 threads
-    if (has_res) {
+    uint2 eres2[HAS_RT ? 4 : 1];   // PK_MAX_UNITS * MT * 64 <= 2048 items = 4 rounds of the 512 threads
+    if constexpr (HAS_RT) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            const int e = min(rr * 512 + tid, n_rs - 1);
-            const int it = e / (MT * 64), m = min((e / 4) % (MT * 16), a.M - 1), c = e & 3;
-            const int n = min(16 * unit_at(it) + 4 * c, a.N - 4);
-            pk_gload8(eres2[rr], a.residual + (a.res_x32 ? x32_offset(m, n) : static_cast<size_t>(m) * a.N + n));
+            const int e = rr * 512 + tid;
+            if (e < n_rs) {
+                const int it = e / (MT * 64), m = min((e / 4) % (MT * 16), a.M - 1), c = e & 3;
+                const int n = min(16 * unit_at(it) + 4 * c, a.N - 4);
+                pk_gload8(eres2[rr], a.residual + (a.res_x32 ? x32_offset(m, n) : static_cast<size_t>(m) * a.N + n));
+            }
         }
     }
-    for (int k = DH; k < D && k < T; ++k) dma_next(k * 1024);
-    PK_STAMP(1);
-    if (T >= D) pk_vmwait<D - DH>();   // activations, tables and the first half of the ring have landed
-    else pk_vmwait<0>();
-    PK_STAMP(2);
-    if constexpr (XL) {
+    PK_STAMP(8);
+    // (2) the ring fill: the first D blocks of the wave's weight stream
+    for (int k = 0; k < D && k < T; ++k) dma_next(k * 1024);
+    // (3) the activation slice of this wave = rows [0, 16 MT) x its XBLK blocks, XBLK * XPB loads in block order.
+    // B fragments: lane (c = r, q) holds x[16 t + c][k .. k + 8), k = blk * KB + 32 s + 8 q; one register array from the load to
+    // the MFMA operand (zeroing, bias, gamma in place).
+    //   x32 image: fragment (u, s, t) is one contiguous KiB.
+    //   row-major: fragment-shaped loads (16 rows x 64 bytes per instruction) are TA-bound (~90 cycles each: ~10 us of prologue
+    //   that way), so the slice comes in row-contiguous pieces -- one instruction = 4 rows x 256 bytes -- into the SAME registers
+    //   and is turned into fragments 4 KiB at a time through a private LDS patch after the wait:
+    //     piece (t, c, i): rows 16 t + 4 i + (lane >> 4), bytes [256 c + 16 (lane & 15), +16) of the slice row
+    //     fragment (u, s, t): lane (r, q) <- row 16 t + r, bytes [XB u + 64 s + 16 q, +16)
+    constexpr int XB = KB * 2;                 // activation bytes per block and row (fp16 x): 64 / 128 / 256
+    constexpr int PAIRB = 256;                 // bytes of one row piece
+    constexpr int NPAIR = XBLK * XB / PAIRB;   // row pieces per row (4 for every format)
+    static_assert(NPAIR * 4 == XBLK * SPB, "register count of pieces == fragments");
+    uint4_t xw[XBLK][SPB][MT];
+    auto piece = [&](int t, int c, int i) -> uint4_t & {   // the register that receives piece (t, c, i): a bijection onto xw
+        const int f = c * 4 + i;
+        return xw[f / SPB][f % SPB][t];
+    };
+    auto xload_block = [&](auto u_tag) {
+        constexpr int u = decltype(u_tag)::value;
 #pragma unroll
-        for (int u = 0; u < XBLK; ++u)
-#pragma unroll
-            for (int s2 = 0; s2 < SPB; ++s2)
-#pragma unroll
-                for (int t = 0; t < MT; ++t) pk_landed(xw[u][s2][t]);
-    } else {
-        // pieces -> fragments through this wave's 4 KiB patch of the (still unused) reduction region: [16 rows][16 chunks] of 16
-        // bytes, chunk index XOR row (conflict-free 16-row column reads); same-wave LDS operations execute in order
-        unsigned char *patch = pk_smem + wave * 4096;
-        const int own0 = blk0 - static_cast<int>(min(static_cast<size_t>(blk0) * XB, static_cast<size_t>(a.K) * 2 - static_cast<size_t>(XBLK) * XB) / XB);
-        // own0 = index, inside the fetched window, of the wave's first own block (0 unless the window was clamped at the row end)
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int c = 0; c < NPAIR; ++c) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = 4 * i + (lane >> 4);
-                    pk_landed(piece(t, c, i));
-                    *reinterpret_cast<uint4_t *>(patch + row * 256 + (((lane & 15) ^ row) << 4)) = piece(t, c, i);
-                }
-                asm volatile("" ::: "memory");
-                // the 4 fragments this 256-byte column range holds, back into the same 4 registers: fragment f = 4 c + j is
-                // (window block f / SPB, step f % SPB); lane (r, q) takes chunk 4 j + q of row r
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    piece(t, c, j) = *reinterpret_cast<const uint4_t *>(patch + r * 256 + (((j * 4 + q) ^ r) << 4));
-                asm volatile("" ::: "memory");
-            }
-        // window block wb = own block u + own0: shift down (own0 > 0 only for the last wave(s) of a clamped window)
-        if (own0 > 0) {
+        for (int s2 = 0; s2 < SPB; ++s2)
 #pragma unroll
             for (int t = 0; t < MT; ++t)
+                pk_gload16_s(xw[u][s2][t], woff, reinterpret_cast<const unsigned char *>(a.x) + (static_cast<size_t>(blkc(u)) * SPB + s2) * 2048 + t * 1024);
+    };
+    if constexpr (XL) {
+        pk_static_for<XBLK>([&](auto u_tag) { xload_block(u_tag); });
+    } else {
+        const size_t slice_bytes = static_cast<size_t>(a.K) * 2;
+        // first byte of the window inside a row, clamped so that every piece stays inside the row
+        const size_t sb0 = min(static_cast<size_t>(blk0) * XB, slice_bytes - static_cast<size_t>(XBLK) * XB);
 #pragma unroll
-                for (int sft = 0; sft < XBLK; ++sft) {   // at most XBLK - 1 single-block shifts
-                    if (sft < own0) {
+        for (int c = 0; c < NPAIR; ++c)
 #pragma unroll
-                        for (int u = 0; u + 1 < XBLK; ++u)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                            for (int s2 = 0; s2 < SPB; ++s2) xw[u][s2][t] = xw[u + 1][s2][t];
-                    }
+                for (int t = 0; t < MT; ++t) {
+                    const unsigned voff = static_cast<unsigned>(min(16 * t + 4 * i + (lane >> 4), a.M - 1)) * static_cast<unsigned>(slice_bytes) + 16 * (lane & 15);
+                    pk_gload16_s(piece(t, c, i), voff, reinterpret_cast<const unsigned char *>(a.x) + sb0 + c * PAIRB);
                 }
+    }
+    PK_STAMP(1);
+    // ================= first wait: the small operands (a wave with a short stream waits for its ring fill as well) ==========
+    if (T >= D) pk_vmwait<XBLK * XPB + D>();
+    else pk_vmwait<XBLK * XPB>();
+    PK_STAMP(2);
+    if constexpr (HAS_ST) {
+        if (tid < n_sc) {
+            if constexpr (FP8) {
+                pk_landed(escale4);
+                *reinterpret_cast<uint4_t *>(etab + tid * 4) = escale4;
+            } else {
+                pk_landed(escale);
+                const half4_t h = __builtin_bit_cast(half4_t, escale);
+                *reinterpret_cast<floatx4 *>(etab + tid * 4) = floatx4{to_f32(h[0]), to_f32(h[1]), to_f32(h[2]), to_f32(h[3])};
+            }
         }
     }
-    // zero what the wave does not own / rows past M (wave-uniform test; the common full case skips 128 selects)
-    if (cnt < XBLK || a.M < 16 * MT) {
-#pragma unroll
-        for (int u = 0; u < XBLK; ++u)
-#pragma unroll
-            for (int s2 = 0; s2 < SPB; ++s2)
-#pragma unroll
-                for (int t = 0; t < MT; ++t)
-                    if (!(u < cnt && 16 * t + r < a.M)) xw[u][s2][t] = uint4_t{0u, 0u, 0u, 0u};
-    }
-    PK_STAMP(3);
-    if (a.gamma || FP8) pk_barrier();   // the patches alias the statistics / gamma staging written below
-    PK_STAMP(4);
-    auto xfrag = [&](const uint4_t &v) { return __builtin_bit_cast(half8_t, v); };
-    if (tid < n_sc) {
-        if constexpr (FP8) {
-            pk_landed(escale4);
-            *reinterpret_cast<uint4_t *>(etab + tid * 4) = escale4;
-        } else {
-            pk_landed(escale);
-            const half4_t h = __builtin_bit_cast(half4_t, escale);
-            *reinterpret_cast<floatx4 *>(etab + tid * 4) = floatx4{to_f32(h[0]), to_f32(h[1]), to_f32(h[2]), to_f32(h[3])};
-        }
-    }
-    if (has_res) {
+    if constexpr (HAS_RT) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             pk_landed(eres2[rr]);
@@ -418,116 +366,176 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
             if (e < n_rs) *reinterpret_cast<uint2 *>(rtab + static_cast<size_t>(e) * 4) = eres2[rr];
         }
     }
+#pragma unroll
+    for (int c = 0; c < GCH; ++c) {
+        pk_landed(graw[c]);
+        pk_landed(praw[c]);
+        const int ch = c * 512 + tid;
+        if (a.gamma && ch < kchunks) {
+            *reinterpret_cast<uint4_t *>(gam + static_cast<size_t>(ch) * 8) = graw[c];
+            if (a.pre_bias) *reinterpret_cast<uint4_t *>(gam + a.K + static_cast<size_t>(ch) * 8) = praw[c];
+        }
+    }
+    pk_barrier();   // gamma / pre_bias staged, tables visible to the epilogue waves
+    PK_STAMP(3);
+
     // Fused RMSNorm (rmsnorm.cu / add_residual_and_rmsnorm.cu semantics): h = (x + pre_bias) * gamma * rsqrt(mean((x + pre_bias)^2) + eps).
     // The register slice is multiplied by gamma only (packed fp16: 4 instructions per fragment); the per-token factor
     // rsqrt(...) is a ROW scale of the product and is applied to the fp32 sums in the epilogue -- per element that is one
-    // fp16 rounding (of x * gamma) where the unfused sequence has one (of the normalised value), and the 32-row prologue drops
-    // from ~1100 to ~400 VALU instructions (it was 4.5 us of the launch: two waves share a SIMD's issue).
+    // fp16 rounding (of x * gamma) where the unfused sequence has one (of the normalised value), and a 32-row prologue drops
+    // from ~1100 to ~400 VALU instructions.
+    const bool need_mask = cnt < XBLK || a.M < 16 * MT;   // wave-uniform; the common full case skips the selects
+    float ss[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) ss[t] = 0.f;
+    auto xfrag = [&](const uint4_t &v) { return __builtin_bit_cast(half8_t, v); };
+    // block u's fragments have landed: zero what the wave does not own / rows past M, pre_bias, sum of squares, gamma
+    auto prep = [&](auto u_tag) {
+        constexpr int u = decltype(u_tag)::value;
+#pragma unroll
+        for (int s2 = 0; s2 < SPB; ++s2)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                pk_landed(xw[u][s2][t]);
+                if (need_mask && !(u < cnt && 16 * t + r < a.M)) xw[u][s2][t] = uint4_t{0u, 0u, 0u, 0u};
+            }
+        if (a.gamma) {
+#pragma unroll
+            for (int s2 = 0; s2 < SPB; ++s2) {
+                const size_t k = static_cast<size_t>(blkc(u)) * KB + s2 * 32 + 8 * q;
+                if (a.pre_bias) {
+                    const half8_t b = *reinterpret_cast<const half8_t *>(gam + a.K + k);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+                        if (u < cnt && 16 * t + r < a.M) xw[u][s2][t] = __builtin_bit_cast(uint4_t, xfrag(xw[u][s2][t]) + b);   // fp16 sum, as the unfused kernel stores it
+                }
+                const half8_t g = *reinterpret_cast<const half8_t *>(gam + k);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    ss[t] = dot8(xfrag(xw[u][s2][t]), xfrag(xw[u][s2][t]), ss[t]);
+                    xw[u][s2][t] = __builtin_bit_cast(uint4_t, xfrag(xw[u][s2][t]) * g);
+                }
+            }
+        }
+    };
     float inv_rms[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) inv_rms[t] = 1.f;
-    if (a.gamma) {
+    auto norm_finalize = [&]() {   // after every block has been prepared: the per-token factor, for the epilogue
+        if (a.gamma) {
 #pragma unroll
-        for (int c = 0; c < GCH; ++c) {
-            pk_landed(graw[c]);
-            pk_landed(praw[c]);
-            const int ch = c * 512 + tid;
-            if (ch < kchunks) {
-                *reinterpret_cast<uint4_t *>(gam + static_cast<size_t>(ch) * 8) = graw[c];
-                *reinterpret_cast<uint4_t *>(gam + a.K + static_cast<size_t>(ch) * 8) = praw[c];
+            for (int t = 0; t < MT; ++t) {
+                ss[t] += __shfl_xor(ss[t], 16, 64);
+                ss[t] += __shfl_xor(ss[t], 32, 64);
+                if (q == 0) stat[(wave * MT + t) * 16 + r] = ss[t];
+            }
+            pk_barrier();
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) tot += stat[(w * MT + t) * 16 + r];
+                inv_rms[t] = rsqrtf(tot / static_cast<float>(a.K) + a.eps);   // of token 16 t + r: this lane's B column AND its D column
             }
         }
-        pk_barrier();
-        if (a.pre_bias) {
-#pragma unroll
-            for (int u = 0; u < XBLK; ++u)
-#pragma unroll
-                for (int s = 0; s < SPB; ++s) {
-                    const half8_t b = *reinterpret_cast<const half8_t *>(gam + a.K + static_cast<size_t>(blkc(u)) * KB + s * 32 + 8 * q);
-#pragma unroll
-                    for (int t = 0; t < MT; ++t)
-                        if (u < cnt && 16 * t + r < a.M) xw[u][s][t] = __builtin_bit_cast(uint4_t, xfrag(xw[u][s][t]) + b);   // fp16 sum, as the unfused kernel stores it
-                }
-        }
-        float ss[MT];
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            ss[t] = 0.f;
-#pragma unroll
-            for (int u = 0; u < XBLK; ++u)
-#pragma unroll
-                for (int s = 0; s < SPB; ++s) ss[t] = dot8(xfrag(xw[u][s][t]), xfrag(xw[u][s][t]), ss[t]);
-            ss[t] += __shfl_xor(ss[t], 16, 64);
-            ss[t] += __shfl_xor(ss[t], 32, 64);
-            if (q == 0) stat[(wave * MT + t) * 16 + r] = ss[t];
-        }
-#pragma unroll
-        for (int u = 0; u < XBLK; ++u)
-#pragma unroll
-            for (int s = 0; s < SPB; ++s) {
-                const half8_t g = *reinterpret_cast<const half8_t *>(gam + static_cast<size_t>(blkc(u)) * KB + s * 32 + 8 * q);
-#pragma unroll
-                for (int t = 0; t < MT; ++t) xw[u][s][t] = __builtin_bit_cast(uint4_t, xfrag(xw[u][s][t]) * g);
-            }
-        pk_barrier();
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            float tot = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) tot += stat[(w * MT + t) * 16 + r];
-            inv_rms[t] = rsqrtf(tot / static_cast<float>(a.K) + a.eps);   // of token 16 t + r: this lane's B column AND its D column
-        }
-    }
-    // fp8: the activation rows are quantised per token to the e4m3 grid (scale amax / 448: quantize_rows_fp8's arithmetic)
-    // and packed 8 bytes per fragment; weights and activations go to v_mfma_f32_16x16x32_fp8_fp8 unconverted
+    };
+
     float xscale[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) xscale[t] = 1.f;
+    {
+        pk_vmwait<0>();   // the activation slice (the ring fill is older: landed as well)
+        if constexpr (!XL) {
+            // pieces -> fragments through this wave's 4 KiB patch of the (still unused) reduction region: [16 rows][16 chunks] of
+            // 16 bytes, chunk index XOR row (conflict-free 16-row column reads); same-wave LDS operations execute in order
+            unsigned char *patch = pk_smem + wave * 4096;
+            const int own0 = blk0 - static_cast<int>(min(static_cast<size_t>(blk0) * XB, static_cast<size_t>(a.K) * 2 - static_cast<size_t>(XBLK) * XB) / XB);
+            // own0 = index, inside the fetched window, of the wave's first own block (0 unless the window was clamped at the row end)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int c = 0; c < NPAIR; ++c) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = 4 * i + (lane >> 4);
+                        pk_landed(piece(t, c, i));
+                        *reinterpret_cast<uint4_t *>(patch + row * 256 + (((lane & 15) ^ row) << 4)) = piece(t, c, i);
+                    }
+                    asm volatile("" ::: "memory");
+                    // the 4 fragments this 256-byte column range holds, back into the same 4 registers: fragment f = 4 c + j is
+                    // (window block f / SPB, step f % SPB); lane (r, q) takes chunk 4 j + q of row r
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        piece(t, c, j) = *reinterpret_cast<const uint4_t *>(patch + r * 256 + (((j * 4 + q) ^ r) << 4));
+                    asm volatile("" ::: "memory");
+                }
+            // window block wb = own block u + own0: shift down (own0 > 0 only for the last wave(s) of a clamped window)
+            if (own0 > 0) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int sft = 0; sft < XBLK; ++sft) {   // at most XBLK - 1 single-block shifts
+                        if (sft < own0) {
+#pragma unroll
+                            for (int u = 0; u + 1 < XBLK; ++u)
+#pragma unroll
+                                for (int s2 = 0; s2 < SPB; ++s2) xw[u][s2][t] = xw[u + 1][s2][t];
+                        }
+                    }
+            }
+        }
+        pk_static_for<XBLK>([&](auto u_tag) { prep(u_tag); });
+    }
+    if constexpr (!XL) pk_barrier();   // the patches alias the reduction slots of the first publish
     if constexpr (FP8) {
-        pk_barrier();  // stat reuse
+        // fp8: the activation rows are quantised per token to the e4m3 grid (scale amax / 448: quantize_rows_fp8's arithmetic;
+        // the per-token norm factor cancels in value / amax, so the codes are those of the normalised row) and packed 8 bytes
+        // per fragment; weights and activations go to v_mfma_f32_16x16x32_fp8_fp8 unconverted
+        float *amx = stat + NW * MT * 16;
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             float amax = 0.f;
 #pragma unroll
             for (int u = 0; u < XBLK; ++u)
 #pragma unroll
-                for (int s = 0; s < SPB; ++s)
+                for (int s2 = 0; s2 < SPB; ++s2)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(to_f32(xfrag(xw[u][s][t])[e])));
+                    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(to_f32(xfrag(xw[u][s2][t])[e])));
             amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
             amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
-            if (q == 0) stat[(wave * MT + t) * 16 + r] = amax;
+            if (q == 0) amx[(wave * MT + t) * 16 + r] = amax;
         }
         pk_barrier();
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             float amax = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) amax = fmaxf(amax, stat[(w * MT + t) * 16 + r]);
+            for (int w = 0; w < NW; ++w) amax = fmaxf(amax, amx[(w * MT + t) * 16 + r]);
             const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
             xscale[t] = sc;   // of token 16 t + r: this lane's B column AND its D column
 #pragma unroll
             for (int u = 0; u < XBLK; ++u)
 #pragma unroll
-                for (int s = 0; s < SPB; ++s) {
+                for (int s2 = 0; s2 < SPB; ++s2) {
                     // the e4m3 fragment (8 bytes) replaces the fp16 one in the low half of its register quad
-                    const half8_t v = xfrag(xw[u][s][t]);
-                    xw[u][s][t][0] = pack4_e4m3(to_f32(v[0]) / sc, to_f32(v[1]) / sc, to_f32(v[2]) / sc, to_f32(v[3]) / sc);
-                    xw[u][s][t][1] = pack4_e4m3(to_f32(v[4]) / sc, to_f32(v[5]) / sc, to_f32(v[6]) / sc, to_f32(v[7]) / sc);
+                    const half8_t v = xfrag(xw[u][s2][t]);
+                    xw[u][s2][t][0] = pack4_e4m3(to_f32(v[0]) / sc, to_f32(v[1]) / sc, to_f32(v[2]) / sc, to_f32(v[3]) / sc);
+                    xw[u][s2][t][1] = pack4_e4m3(to_f32(v[4]) / sc, to_f32(v[5]) / sc, to_f32(v[6]) / sc, to_f32(v[7]) / sc);
                 }
         }
     }
-    pk_barrier();   // the prologue's statistics / gamma staging alias the reduction slots; tables visible to the epilogue waves
+    PK_STAMP(4);
 
-    PK_STAMP(5);
     // ---- reduction + epilogue of a finished unit ----
     floatx4 acc[MT];
-    auto publish = [&](const int j, const int parity) {
+    auto publish = [&](const floatx4 (&av)[MT], const int j, const int parity) {
         floatx4 *slot = red + static_cast<size_t>(parity) * NW * TPI * MT * 64;
 #pragma unroll
-        for (int t = 0; t < MT; ++t) slot[(wave * TPI * MT + j * MT + t) * 64 + lane] = acc[t];
+        for (int t = 0; t < MT; ++t) slot[(wave * TPI * MT + j * MT + t) * 64 + lane] = av[t];
     };
     auto finish = [&](const int it, const int parity) {
         const floatx4 *slot = red + static_cast<size_t>(parity) * NW * TPI * MT * 64;
-        pk_barrier();  // one barrier per unit: the other parity slot is free for the next unit
+        pk_barrier();  // every wave's partial tile is in the slot (two parities: the other one is free for the next unit)
         if (wave < MT) {
             const int unit = unit_at(it);
             const int t = wave, m = 16 * t + r;
@@ -541,7 +549,6 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
             const int n0 = 16 * unit + 4 * q;  // PLAIN / SLAB: output features n0..n0+3; SWIGLU: inter index
             float xs = t == 0 ? inv_rms[0] : inv_rms[MT - 1];               // MT <= 2: no runtime-indexed register array
             if constexpr (FP8) xs *= t == 0 ? xscale[0] : xscale[MT - 1];
-            constexpr bool SCALED = WF == PK_I8 || FP8;
             if constexpr (EPI == PK_EPI_SLAB) {
                 // unscaled partial sums (the weight-row scale is applied by the reduce launch)
                 if (m < a.M && n0 < a.N)
@@ -577,15 +584,16 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
                     *reinterpret_cast<half4_t *>(a.y + (a.y_x32 ? x32_offset(m, n0) : static_cast<size_t>(m) * a.N + n0)) = y4;
             }
         }
+        if constexpr (NPAR == 1) pk_barrier();   // one slot set: the reducers are done with it before the next unit publishes
     };
 
-    // ---- main loop over the block stream, software-pipelined by one block: while block k is multiplied the LDS read of
-    //      block k + 1 is in flight and the DMA of block k + D has been issued into the slot block k has just left ----
+    // ---- the block stream, software-pipelined by one block: while block k is multiplied the LDS read of block k + 1 is in
+    //      flight and the DMA of block k + D has been issued into the slot block k has just left ----
     // The kernel is instruction-issue bound before it is HBM bound (PMC: the first form of this loop, with its per-block
     // index arithmetic and tail tests, spent ~120 instructions per KiB and kept the SIMDs 78 % busy at 3 TB/s), so a tile whose
     // blocks are all in the steady state (the common case) runs a branch-free body: no tail tests, no per-block ownership
     // test, two alternating block registers instead of a copy.
-    unsigned sb = 0;         // ring slot (byte offset) of stream element kk
+    unsigned sb = 0;         // ring slot (byte offset) of the stream element being multiplied
     int kk = 0;              // stream index of the first block of the current tile
     const unsigned lds_rd = static_cast<unsigned>(wave * (D * 1024) + lane * 16);
     auto lds_block = [&](const unsigned slot_bytes) { return *reinterpret_cast<const uint4_t *>(ring_all + lds_rd + slot_bytes); };
@@ -593,12 +601,8 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
     uint4_t wq[2];           // block kk in wq[0] at every tile start
     wq[0] = uint4_t{0u, 0u, 0u, 0u};
     wq[1] = wq[0];
-    if (T > 0) {   // (the prologue's wait retired the first half of the ring fill)
-        wq[0] = lds_block(0);
-        pk_landed(wq[0]);
-    }
-    PK_STAMP(6);
-    auto mma_block = [&](auto u_tag, const uint4_t &w, const half8_t (&af)[(FP8 || WF == PK_F16) ? 1 : SPB]) {
+    if (T > 0) wq[0] = lds_block(0);
+    auto mma_into = [&](floatx4 (&acc)[MT], auto u_tag, const uint4_t &w, const half8_t (&af)[(FP8 || WF == PK_F16) ? 1 : SPB]) {
         constexpr int u = decltype(u_tag)::value;
         if constexpr (FP8) {
 #pragma unroll
@@ -621,10 +625,14 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
                 for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s], xfrag(xw[u][s][t]), acc[t], 0, 0, 0);
         }
     };
-    int parity = 0;
-    for (int i = 0; i < L; ++i) {
+    auto mma_block = [&](auto u_tag, const uint4_t &w, const half8_t (&af)[(FP8 || WF == PK_F16) ? 1 : SPB]) { mma_into(acc, u_tag, w, af); };
+    auto dequant = [&](const uint4_t &w, half8_t (&af)[(FP8 || WF == PK_F16) ? 1 : SPB]) {
+        if constexpr (!FP8 && WF != PK_F16) {
 #pragma unroll
-        for (int t = 0; t < MT; ++t) acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < SPB; ++s) af[s] = pk_afrag<WF>(w, s);
+        }
+    };
+    auto tile_blocks = [&]() {
         if (cnt == XBLK && kk + XBLK + D <= T) {
             // steady tile: every block's refill (element + D) and successor (element + 1) exist and are D - 1 deep
             pk_static_for<XBLK>([&](auto u_tag) {
@@ -637,15 +645,32 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
                 pk_vmwait<D - 2>();
                 wq[(u + 1) & 1] = lds_block(nsb);
                 half8_t af[(FP8 || WF == PK_F16) ? 1 : SPB];
-                if constexpr (!FP8 && WF != PK_F16) {
-#pragma unroll
-                    for (int s = 0; s < SPB; ++s) af[s] = pk_afrag<WF>(w, s);
-                }
+                dequant(w, af);
                 dma_next(sb);
                 sb = nsb;
                 mma_block(u_tag, w, af);
             });
             kk += XBLK;
+        } else if (kk + cnt + D <= T) {
+            // the same steady body for a wave that owns fewer blocks than its register slice holds (K split over workgroups:
+            // the 7B down projection gives its waves 5 or 6 of 8)
+            pk_static_for<XBLK>([&](auto u_tag) {
+                constexpr int u = decltype(u_tag)::value;
+                if (u < cnt) {   // wave-uniform
+                    uint4_t &w = wq[u & 1];
+                    pk_landed(w);
+                    const unsigned nsb = next_slot(sb);
+                    pk_vmwait<D - 2>();
+                    wq[(u + 1) & 1] = lds_block(nsb);
+                    half8_t af[(FP8 || WF == PK_F16) ? 1 : SPB];
+                    dequant(w, af);
+                    dma_next(sb);
+                    sb = nsb;
+                    mma_block(u_tag, w, af);
+                }
+            });
+            if (cnt & 1) wq[0] = wq[1];   // the next tile's first block is expected in wq[0]
+            kk += cnt;
         } else {
             pk_static_for<XBLK>([&](auto u_tag) {
                 constexpr int u = decltype(u_tag)::value;
@@ -653,10 +678,7 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
                     uint4_t w = wq[0];
                     pk_landed(w);
                     half8_t af[(FP8 || WF == PK_F16) ? 1 : SPB];
-                    if constexpr (!FP8 && WF != PK_F16) {
-#pragma unroll
-                        for (int s = 0; s < SPB; ++s) af[s] = pk_afrag<WF>(w, s);
-                    }
+                    dequant(w, af);
                     const int k = kk + u;
                     if (k + D < T) dma_next(sb);
                     sb = next_slot(sb);
@@ -670,15 +692,24 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
             });
             kk += cnt;
         }
-        if (i == 0) PK_STAMP(7);
-        publish(i % TPI, parity);
+    };
+    int parity = 0;
+    for (int i = 0; i < L; ++i) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+        tile_blocks();
+        if (i == 0) {
+            PK_STAMP(5);
+            norm_finalize();
+        }
+        publish(acc, i % TPI, parity);
         if (i % TPI == TPI - 1) {
             finish(i / TPI, parity);
-            parity ^= 1;
+            if constexpr (NPAR == 2) parity ^= 1;
         }
-        if (i == 0) PK_STAMP(8);
+        if (i == 0) PK_STAMP(6);
     }
-    PK_STAMP(9);
+    PK_STAMP(7);
 }
 
 // ---- packers: row-major weights of the reference layout -> tile-packed image ----

@@ -119,21 +119,23 @@ size_t pk_slab_floats(int wf, int M, int K, int N) {
     return ks > 1 ? static_cast<size_t>(ks) * M * N : 0;
 }
 
-template <int MT, int WF, int EPI, bool XL> static void pk_launch_x(const PkArgs &a, const PkPlan &p, hipStream_t st) {
-    // reduction slots + per-wave DMA ring + epilogue tables (pk_lds); the largest carve of this instantiation is registered once
-    constexpr int lds_max = pk_lds(MT, EPI, PK_NORM_MAX_K, EPI == PK_EPI_PLAIN).total;
-    static_assert(lds_max <= 160 * 1024, "LDS carve exceeds the CU");
+template <int MT, int WF, int EPI, int XM> static void pk_launch_x(const PkArgs &a, const PkPlan &p, hipStream_t st) {
+    // reduction slots + per-wave DMA ring + epilogue tables + norm staging (pk_lds); the opt-in limit is registered once
+    constexpr int lds_max = 160 * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pk_mfma_kernel<MT, WF, EPI, XL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pk_mfma_kernel<MT, WF, EPI, XM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
         attr_set = true;
     }
-    const int lds = pk_lds(MT, EPI, a.gamma ? a.K : 0, EPI == PK_EPI_PLAIN && a.residual != nullptr).total;
-    pk_mfma_kernel<MT, WF, EPI, XL><<<dim3(p.gx, p.KS), 512, lds, st>>>(a);
+    const int lds = pk_lds(MT, EPI, a.gamma ? (a.pre_bias ? 2 * a.K : a.K) : 0, EPI == PK_EPI_PLAIN && a.residual != nullptr).total;
+    pk_mfma_kernel<MT, WF, EPI, XM><<<dim3(p.gx, p.KS), 512, lds, st>>>(a);
 }
 template <int MT, int WF, int EPI> static void pk_launch_t(const PkArgs &a, const PkPlan &p, hipStream_t st) {
-    if (a.x_x32) pk_launch_x<MT, WF, EPI, true>(a, p, st);
-    else pk_launch_x<MT, WF, EPI, false>(a, p, st);
+    if (!a.x_x32) {
+        pk_launch_x<MT, WF, EPI, 0>(a, p, st);
+        return;
+    }
+    pk_launch_x<MT, WF, EPI, 1>(a, p, st);
 }
 template <int WF> static void pk_launch_f(int mt, int epi, const PkArgs &a, const PkPlan &p, hipStream_t st) {
     if (mt == 1) {
@@ -156,7 +158,7 @@ int pk_linear(int wf, const half_t *x, const void *Wp, const void *scale, half_t
     if (!pk_eligible(wf, M, K, N, epi) || (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(Wp) | reinterpret_cast<uintptr_t>(gamma) |
                                             reinterpret_cast<uintptr_t>(pre_bias)) % 16 ||
         reinterpret_cast<uintptr_t>(y) % 8 || reinterpret_cast<uintptr_t>(residual) % 8 ||
-        (wf != PK_F16 && !scale) || (gamma && K > PK_NORM_MAX_K)) {
+        (wf != PK_F16 && !scale) || (gamma && K > PK_NORM_MAX_K) || (gamma && residual) /* LDS: norm staging + residual table */) {
         set_error("linear(packed): unsupported shape / alignment M=%d K=%d N=%d", M, K, N);
         return LLMIE_ERR_UNSUPPORTED;
     }
@@ -164,6 +166,10 @@ int pk_linear(int wf, const half_t *x, const void *Wp, const void *scale, half_t
     PkPlan p;
     if (!pk_plan(wf, K, units, epi != PK_EPI_SWIGLU && !gamma && wf != PK_FP8 /* per-token scales: no K split */, &p)) {
         set_error("linear(packed): K=%d does not fit the register-resident activation slice%s", K, gamma ? " (fused norm: no K split)" : "");
+        return LLMIE_ERR_UNSUPPORTED;
+    }
+    if (pk_lds((M + 15) / 16, epi, gamma ? (pre_bias ? 2 * K : K) : 0, epi == PK_EPI_PLAIN && residual).total > 160 * 1024) {
+        set_error("linear(packed): K=%d with this fused norm / residual does not fit the LDS carve", K);
         return LLMIE_ERR_UNSUPPORTED;
     }
     const int x_x32 = x32_flags & PK_X32_X, y_x32 = (x32_flags & PK_X32_Y) ? 1 : 0, res_x32 = (x32_flags & PK_X32_RES) ? 1 : 0;

@@ -248,7 +248,12 @@ def test_x32_convert_bit_exact(llmie, M, C):
 
 @pytest.mark.parametrize("fmt", ["int8", "f16"])
 @pytest.mark.parametrize("M,K,N,mode", [(32, 4096, 4096, "resid"), (21, 4096, 12288, "norm"), (32, 4096, 22016, "swiglu"),
-                                        (32, 11008, 4096, "resid"), (9, 4096, 512, "plain")])
+                                        (32, 11008, 4096, "resid"), (9, 4096, 512, "plain"),
+                                        # block-major first pass over 2 / 3 / 4 tiles, then tile-major left-overs; waves that own
+                                        # fewer blocks than their register slice holds (K 2048), SwiGLU with one unit per workgroup
+                                        (32, 4096, 8192, "plain"), (16, 4096, 8192, "swiglu"), (32, 4096, 10240, "norm"),
+                                        (32, 4096, 32000, "plain"), (32, 2048, 12288, "plain"), (27, 2048, 16384, "resid"),
+                                        (32, 5120, 15360, "resid"), (32, 3072, 24576, "swiglu")])
 def test_linear_packed_x32_layout_is_bit_identical(llmie, fmt, M, K, N, mode):
     """the x32 activation layout changes addresses, not arithmetic: x / y / residual in x32 give exactly the row-major result"""
     rng = np.random.default_rng(48)

@@ -33,7 +33,7 @@ for mode, tiles in (("plain", 1), ("plain", 3), ("norm", 3)):
     st = buf.reshape(256, 8, 16)[:, :, :10].astype(np.int64)
     t0 = st[:, :, 0].min()
     rel = (st - t0) * 0.01   # us (100 MHz)
-    names = ["start", "loads issued", "x landed", "transposed", "barrier", "prologue end", "first block", "tile0 mma", "tile0 done", "end"]
+    names = ["start", "loads issued", "first wait", "staged+barrier", "prologue end", "tile0 blocks", "tile0 done", "end", "pre issued", "x issued"]
     print("== %s, %d tile(s)/WG: median over waves [min .. max] us since the first wave started" % (mode, tiles))
     for i, n in enumerate(names):
         v = rel[:, :, i].reshape(-1)
