@@ -103,16 +103,23 @@ int llmie_add_residual(const void *resid, void *out, int num_tokens, int hidden,
 /* replaces launchLinearGemm            src/kernels/linear.cu:10-87 (+ cublas_utils.cpp:29-93)
  * trans_b != 0: y[M,N] = x[M,K] . W[N,K]^T ; trans_b == 0: y = x . W[K,N].
  * bias (nullable, [N]) and residual (nullable, [M,N], may alias y) are fused epilogues the
- * reference does in separate kernels; pass NULL for the plain reference semantics. */
+ * reference does in separate kernels; pass NULL for the plain reference semantics.
+ * workspace: the counterpart of the scratch the reference's cublasWrapper argument owns (cublas_utils.cpp:29-93) -- caller-owned
+ * fp32 slabs of the split-K forms (decode / short-prefill batches of up to 192 rows), llmie_linear_workspace_bytes() bytes,
+ * 16-byte aligned.  NOTHING on the compute path allocates: a first call may already run under hipGraph capture.  NULL: fp16
+ * runs its non-split kernels (slower at 8 < M <= 192); a non-NULL workspace that is too small is LLMIE_ERR_WORKSPACE. */
+size_t llmie_linear_workspace_bytes(llmie_weight_format fmt, int M, int K, int N);
 int llmie_linear(const void *x, const void *w, void *y, int M, int K, int N, int trans_b,
                  const void *bias, const void *residual,
-                 llmie_dtype dtype, llmie_stream stream);
+                 llmie_dtype dtype, void *workspace, size_t workspace_bytes, llmie_stream stream);
 
 /* replaces launchLinearGemm(gate_and_up) + launchSiluAndMul   src/layers/ffn.cpp:105-122,
  * src/kernels/silu_and_mul.cu:61-82 in one kernel: w is the fused gate_up matrix [2I,K]
- * (rows [0,I) gate, [I,2I) up); y[M,I] = silu(x.Wg^T) * (x.Wu^T).  fp16 only (decode path). */
+ * (rows [0,I) gate, [I,2I) up); y[M,I] = silu(x.Wg^T) * (x.Wu^T).  fp16 only (decode path).
+ * workspace: llmie_linear_workspace_bytes(LLMIE_W_F16, M, K, two_inter), see llmie_linear; without it 64 < M needs
+ * prefill-sized shapes. */
 int llmie_linear_swiglu(const void *x, const void *w, void *y, int M, int K, int two_inter,
-                        llmie_dtype dtype, llmie_stream stream);
+                        llmie_dtype dtype, void *workspace, size_t workspace_bytes, llmie_stream stream);
 
 /* replaces launchLinearStridedBatchGemm src/kernels/linear.cu:89-158 (+ cublas_utils.cpp:95-154)
  * per batch i: C_i[m,n] = A_i[m,k] . B_i  (B_i is [n,k] if trans_b else [k,n]); dense strides */
@@ -207,24 +214,27 @@ int llmie_sampling(const int32_t *topk_id, const void *topk_val, int32_t *seq_le
 /*    README.md:36-39, linear.cuh:12 TODO)                                    */
 /* ------------------------------------------------------------------------- */
 
-/* y[M,N] = x[M,K] . (scale[n]*Wq[n,k])^T ; x,y,scale,bias fp16; Wq int8 row-major [N,K] */
+/* y[M,N] = x[M,K] . (scale[n]*Wq[n,k])^T ; x,y,scale,bias fp16; Wq int8 row-major [N,K].
+ * workspace: llmie_linear_workspace_bytes(LLMIE_W_INT8 / LLMIE_W_INT4, M, K, N) bytes of caller-owned split-K slabs (see
+ * llmie_linear); without it int8 serves M <= 64 and int4 the GEMV sizes only. */
 int llmie_linear_w8a16(const void *x, const int8_t *wq, const void *scale, void *y,
                        int M, int K, int N, const void *bias, const void *residual,
-                       llmie_stream stream);
+                       void *workspace, size_t workspace_bytes, llmie_stream stream);
 /* int4: two nibbles per byte (low nibble = even k), value = nibble-8, scale[n, k/group] fp16 */
 int llmie_linear_w4a16(const void *x, const uint8_t *wq, const void *scale, void *y,
                        int M, int K, int N, int group, const void *bias, const void *residual,
-                       llmie_stream stream);
+                       void *workspace, size_t workspace_bytes, llmie_stream stream);
 /* fp8 e4m3 (OCP) weights [N,K] with per-row fp32 scale; x fp16 is quantised per token to e4m3
  * on the fly (scale = amax/448); y[m,n] = w_scale[n] * x_scale[m] * sum_k wq[n,k] xq[m,k], fp32 accumulate; y fp16.
  * M <= 8: K-split GEMV (same arithmetic on the VALU); 8 < M: split-K fp8 MFMA (K % 256 == 0, K >= 512; 64 < M <= 128 rows per
  * pass take the 128-row LDS-DMA form);
  * prefill-sized M x N (>= 192 tiles of 256 x 256 or 256 x 128): tiled v_mfma_scale_f32_16x16x128_f8f6f4 GEMM
- * (K % 128 == 0).  workspace = quantised activations + per-token scales. */
+ * (K % 128 == 0).  workspace = quantised activations + per-token scales + the fp32 slabs of the split-K form, all caller-owned:
+ * llmie_linear_fp8_workspace_bytes(M, K, N) bytes, 256-byte aligned. */
 int llmie_linear_fp8(const void *x, const uint8_t *w_fp8, const float *w_scale, void *y,
                      int M, int K, int N, const void *bias, const void *residual,
                      void *workspace, size_t workspace_bytes, llmie_stream stream);
-size_t llmie_linear_fp8_workspace_bytes(int M, int K);
+size_t llmie_linear_fp8_workspace_bytes(int M, int K, int N);   /* N = 0: the activation part only (llmie_linear_fp8_swiglu) */
 /* y[M, two_inter/2] = silu(gate) * up of the fused gate_up projection in fp8 (ffn.cpp:105-122 in one launch after the
  * activation quantisation); prefill-sized shapes only (LLMIE_ERR_UNSUPPORTED otherwise: use llmie_linear_fp8 +
  * llmie_silu_and_mul) */

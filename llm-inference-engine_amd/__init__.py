@@ -45,8 +45,9 @@ _SIGS = {
     "llmie_rmsnorm": [_vp, _vp, _vp, _f, _i, _i, _i, _vp],
     "llmie_fused_add_bias_residual_rmsnorm": [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp],
     "llmie_add_residual": [_vp, _vp, _i, _i, _i, _vp],
-    "llmie_linear": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],
-    "llmie_linear_swiglu": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "llmie_linear_workspace_bytes": [_i, _i, _i, _i],
+    "llmie_linear": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _sz, _vp],
+    "llmie_linear_swiglu": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp],
     "llmie_batched_gemm": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "llmie_qkv_bias_transpose_rope": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "llmie_rope_decode": [_vp, _i, _i, _i, _i, _i, _vp, _i, _f, _i, _vp],
@@ -61,10 +62,10 @@ _SIGS = {
     "llmie_silu_and_mul": [_vp, _vp, _i, _i, _i, _vp],
     "llmie_topk": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "llmie_sampling": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp],
-    "llmie_linear_w8a16": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
-    "llmie_linear_w4a16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "llmie_linear_w8a16": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp],
+    "llmie_linear_w4a16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp],
     "llmie_linear_fp8": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp],
-    "llmie_linear_fp8_workspace_bytes": [_i, _i],
+    "llmie_linear_fp8_workspace_bytes": [_i, _i, _i],
     "llmie_linear_fp8_swiglu": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp],
     "llmie_packed_weight_bytes": [_i, _i, _i, _i],
     "llmie_packed_scale_bytes": [_i, _i, _i, _i],
@@ -97,6 +98,7 @@ _SIGS = {
 _RESTYPES = {
     "llmie_decoder_mha_workspace_bytes": _sz,
     "llmie_linear_fp8_workspace_bytes": _sz,
+    "llmie_linear_workspace_bytes": _sz,
     "llmie_packed_weight_bytes": _sz,
     "llmie_x32_bytes": _sz,
     "llmie_packed_scale_bytes": _sz,
@@ -192,17 +194,47 @@ def add_residual(resid, out):
     _check(lib().llmie_add_residual(_p(resid), _p(out), out.shape[0], out.shape[1], _dt(out), _st()), "add_residual")
 
 
-def linear(x, w, y, trans_b=True, bias=None, residual=None):
+def linear_workspace_bytes(fmt, M, K, N):
+    """bytes of caller-owned split-K slab scratch llmie_linear / _swiglu / _w8a16 / _w4a16 use for this shape (0: none)"""
+    return lib().llmie_linear_workspace_bytes(fmt, M, K, N)
+
+
+_scratch = {}
+
+
+def _auto_ws(fmt, M, K, N, device):
+    """workspace="auto": one grow-only torch buffer per device, owned by this module (the C library itself never allocates)"""
+    need = linear_workspace_bytes(fmt, M, K, N)
+    if need == 0:
+        return None
+    import torch
+    buf = _scratch.get(device)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(need, dtype=torch.uint8, device=device)
+        _scratch[device] = buf
+    return buf
+
+
+def _ws_args(workspace, fmt, M, K, N, device):
+    if isinstance(workspace, str):
+        workspace = _auto_ws(fmt, M, K, N, device)
+    return _p(workspace), (workspace.numel() * workspace.element_size() if workspace is not None else 0)
+
+
+def linear(x, w, y, trans_b=True, bias=None, residual=None, workspace="auto"):
+    """workspace: a device tensor of linear_workspace_bytes(W_F16, M, K, N) bytes, None (non-split kernels), or the string auto"""
     M, K = x.shape[0], x.numel() // x.shape[0]
     N = y.numel() // y.shape[0]
-    _check(lib().llmie_linear(_p(x), _p(w), _p(y), M, K, N, int(trans_b), _p(bias), _p(residual), _dt(x), _st()),
+    wp, wb = _ws_args(workspace, W_F16, M, K, N, x.device)
+    _check(lib().llmie_linear(_p(x), _p(w), _p(y), M, K, N, int(trans_b), _p(bias), _p(residual), _dt(x), wp, wb, _st()),
            "linear")
     return y
 
 
-def linear_swiglu(x, w_gate_up, y):
+def linear_swiglu(x, w_gate_up, y, workspace="auto"):
+    wp, wb = _ws_args(workspace, W_F16, x.shape[0], x.shape[1], w_gate_up.shape[0], x.device)
     _check(lib().llmie_linear_swiglu(_p(x), _p(w_gate_up), _p(y), x.shape[0], x.shape[1], w_gate_up.shape[0],
-                                     _dt(x), _st()), "linear_swiglu")
+                                     _dt(x), wp, wb, _st()), "linear_swiglu")
     return y
 
 
@@ -427,15 +459,17 @@ def quantize_w4(w, wq, scale, group):
     _check(lib().llmie_quantize_w4(_p(w), _p(wq), _p(scale), w.shape[0], w.shape[1], group, _st()), "quantize_w4")
 
 
-def linear_w8a16(x, wq, scale, y, bias=None, residual=None):
+def linear_w8a16(x, wq, scale, y, bias=None, residual=None, workspace="auto"):
+    wp, wb = _ws_args(workspace, W_INT8, x.shape[0], x.shape[1], wq.shape[0], x.device)
     _check(lib().llmie_linear_w8a16(_p(x), _p(wq), _p(scale), _p(y), x.shape[0], x.shape[1], wq.shape[0], _p(bias),
-                                    _p(residual), _st()), "linear_w8a16")
+                                    _p(residual), wp, wb, _st()), "linear_w8a16")
     return y
 
 
-def linear_w4a16(x, wq, scale, y, group, bias=None, residual=None):
+def linear_w4a16(x, wq, scale, y, group, bias=None, residual=None, workspace="auto"):
+    wp, wb = _ws_args(workspace, W_INT4, x.shape[0], x.shape[1], wq.shape[0], x.device)
     _check(lib().llmie_linear_w4a16(_p(x), _p(wq), _p(scale), _p(y), x.shape[0], x.shape[1], wq.shape[0], group,
-                                    _p(bias), _p(residual), _st()), "linear_w4a16")
+                                    _p(bias), _p(residual), wp, wb, _st()), "linear_w4a16")
     return y
 
 
@@ -454,8 +488,9 @@ def kv_pages_copy(dense, pool, block_table, ctx_len, to_pages):
            "kv_pages_copy")
 
 
-def linear_fp8_workspace_bytes(M, K):
-    return lib().llmie_linear_fp8_workspace_bytes(M, K)
+def linear_fp8_workspace_bytes(M, K, N=0):
+    """N = 0: the activation part only (linear_fp8_swiglu, prefill-sized linear_fp8)"""
+    return lib().llmie_linear_fp8_workspace_bytes(M, K, N)
 
 
 def linear_fp8_swiglu(x, wq, wscale, y, workspace):

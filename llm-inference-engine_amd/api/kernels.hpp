@@ -9,17 +9,30 @@
 
 typedef void *llmieBlasHandle_t;  // stands where the reference takes cublasHandle_t / cublasLtHandle_t (ignored)
 
-// GEMM context: name and constructor shape of the reference's CublasWrapper; holds no vendor library.
+// GEMM context: name and constructor shape of the reference's CublasWrapper; holds no vendor library.  Like the reference's
+// (whose cuBLAS handle owns its workspace) it owns the scratch the GEMMs use: fp32 split-K slabs, allocated HERE, once -- the
+// C ABI never allocates on the compute path.  A shape that needs more than the wrapper holds runs the non-split kernels.
 class CublasWrapper {
 private:
     llmie_dtype dtype_ = LLMIE_F32;
+    void *ws_ = nullptr;
+    size_t ws_bytes_ = 0;
 
 public:
-    CublasWrapper(llmieBlasHandle_t = nullptr, llmieBlasHandle_t = nullptr) {}
-    ~CublasWrapper() = default;
+    explicit CublasWrapper(llmieBlasHandle_t = nullptr, llmieBlasHandle_t = nullptr, size_t workspace_bytes = size_t(128) << 20) {
+        if (workspace_bytes && hipMalloc(&ws_, workspace_bytes) == hipSuccess) ws_bytes_ = workspace_bytes;
+    }
+    ~CublasWrapper() {
+        if (ws_) (void)hipFree(ws_);
+    }
+    CublasWrapper(const CublasWrapper &) = delete;
+    CublasWrapper &operator=(const CublasWrapper &) = delete;
     void setFP32GemmConfig() { dtype_ = LLMIE_F32; }
     void setFP16GemmConfig() { dtype_ = LLMIE_F16; }
     llmie_dtype dtype() const { return dtype_; }
+    // the wrapper's scratch if it covers `need` bytes, else none
+    void *workspace(size_t need) const { return need <= ws_bytes_ ? ws_ : nullptr; }
+    size_t workspace_bytes(size_t need) const { return need <= ws_bytes_ ? ws_bytes_ : 0; }
 };
 
 namespace llmie_api {
@@ -99,7 +112,6 @@ void launchAddResidual(TensorWrapper<T> *residual, TensorWrapper<T> *decoder_out
 template <typename T>
 void launchLinearGemm(TensorWrapper<T> *input, BaseWeight<T> *weight, TensorWrapper<T> *output,
                       CublasWrapper *cublas_wrapper, bool trans_a = false, bool trans_b = false) {
-    (void)cublas_wrapper;
     LLM_CHECK_WITH_INFO(!trans_a, "trans_a is not used by any caller of the reference and is not supported");
     const int Am = input->shape[0];
     const int An = input->shape.size() == 3 ? input->shape[1] * input->shape[2] : input->shape[1];
@@ -109,8 +121,10 @@ void launchLinearGemm(TensorWrapper<T> *input, BaseWeight<T> *weight, TensorWrap
     if (trans_b) std::swap(opBm, opBn);
     LLM_CHECK_WITH_INFO(An == opBm, "2nd dim of weight MUST = 1st dim of input");
     LLM_CHECK_WITH_INFO(Am == Cm && opBn == Cn, "output shape should be equal to weight shape");
+    const size_t need = (cublas_wrapper && trans_b && std::is_same<T, half>::value) ? llmie_linear_workspace_bytes(LLMIE_W_F16, Cm, An, Cn) : 0;
     LLMIE_CALL(llmie_linear(input->data, weight->data, output->data, Cm, An, Cn, trans_b ? 1 : 0, nullptr, nullptr,
-                            llmie_api::dtype_of<T>(), llmie_api::st()));
+                            llmie_api::dtype_of<T>(), need ? cublas_wrapper->workspace(need) : nullptr,
+                            need ? cublas_wrapper->workspace_bytes(need) : 0, llmie_api::st()));
 }
 
 // linear.cuh:23-29: per (b,h): C = A.B or A.B^T

@@ -235,8 +235,11 @@ public:
         if (std::is_same<T, half>::value && weights->gate_and_up.is_transposed && rows <= 64 &&
             hidden_units % 32 == 0 && intermediate_size % 16 == 0) {
             // decode: gate/up GEMV with the SwiGLU epilogue (one kernel instead of GEMM + launchSiluAndMul)
+            const size_t need = cublas_wrapper ? llmie_linear_workspace_bytes(LLMIE_W_F16, rows, hidden_units, 2 * intermediate_size) : 0;
             LLMIE_CALL(llmie_linear_swiglu(ffn_input->wrap<T>()->data, weights->gate_and_up.data, down_proj_input->data,
-                                           rows, hidden_units, 2 * intermediate_size, LLMIE_F16, llmie_api::st()));
+                                           rows, hidden_units, 2 * intermediate_size, LLMIE_F16,
+                                           need ? cublas_wrapper->workspace(need) : nullptr,
+                                           need ? cublas_wrapper->workspace_bytes(need) : 0, llmie_api::st()));
         } else {
             launchLinearGemm(ffn_input->wrap<T>(), &weights->gate_and_up, swiglu_input, cublas_wrapper, false,
                              weights->gate_and_up.is_transposed);

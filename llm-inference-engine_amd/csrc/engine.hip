@@ -31,6 +31,7 @@ struct llmie_decoder {
     float2 *rope_table;  // [max_seq_len][head_size/2] (cos, sin), host-computed at create
     void *fp8_ws;        // LLMIE_W_FP8 engines: activation quantisation + split-K scratch of llmie_linear_fp8
     size_t fp8_ws_bytes;
+    SlabWs slab_ws;      // fp32 slabs of the split-K projections (batch path, row-major engines)
     int32_t *tickets;    // [max_batch, kv_head_num] arrival counters of the in-launch attention merge (zero between launches)
     // packed-weight batch path (gemv_max < batch <= 32): tile-packed images of the four matrices of every layer (built once at
     // create time into the caller's workspace: the MI355X's 288 GB buy a second, stream-friendly copy of the weights), the
@@ -148,7 +149,35 @@ static PackedCarve packed_carve(const llmie_decoder_config *c, int wf) {
     return p;
 }
 
-static size_t carve(const llmie_decoder_config *c, size_t *offs /*[11]*/) {
+// fp32 floats of split-K slab scratch the engine's projections can need at up to `rows` activation rows (0: none)
+static size_t engine_slab_floats(const llmie_decoder_config *c, int rows) {
+    int wbits;
+    switch (c->wfmt) {
+        case LLMIE_W_F16: wbits = 16; break;
+        case LLMIE_W_INT8: wbits = 8; break;
+        case LLMIE_W_INT4: wbits = 4; break;
+        case LLMIE_W_FP8: wbits = WF_FP8; break;
+        default: return 0;
+    }
+    if (c->dtype != LLMIE_F16) return 0;
+    const int H = c->head_num * c->head_size, QKV = (c->head_num + 2 * c->kv_head_num) * c->head_size, I = c->inter_size;
+    const int shapes[4][2] = {{H, QKV}, {H, H}, {H, 2 * I}, {I, H}};
+    size_t m = 0;
+    for (int r = 1; r <= rows; r = r < 16 ? r + 1 : r + 16) {   // the plan changes with the row count (forms, slices)
+        const int rr = r > rows ? rows : r;
+        for (const auto &sh : shapes) {
+            const size_t f = linear_splitk_ws_floats(wbits, rr, sh[0], sh[1]);
+            m = f > m ? f : m;
+        }
+    }
+    for (const auto &sh : shapes) {
+        const size_t f = linear_splitk_ws_floats(wbits, rows, sh[0], sh[1]);
+        m = f > m ? f : m;
+    }
+    return m;
+}
+
+static size_t carve(const llmie_decoder_config *c, size_t *offs /*[12]*/) {
     const size_t e = c->dtype == LLMIE_F16 ? 2 : 4;
     const size_t B = c->max_batch, H = static_cast<size_t>(c->head_num) * c->head_size;
     const size_t QKV = static_cast<size_t>(c->head_num + 2 * c->kv_head_num) * c->head_size;
@@ -165,14 +194,15 @@ static size_t carve(const llmie_decoder_config *c, size_t *offs /*[11]*/) {
     offs[8] = k.take(static_cast<size_t>(c->max_batch) * c->kv_head_num * sizeof(int32_t));         // merge tickets
     const int kmax = c->inter_size > static_cast<int>(H) ? c->inter_size : static_cast<int>(H);
     // fp8: three activation-quantisation units (normed input, attention output, SwiGLU output), see decoder_forward
-    offs[9] = k.take(c->wfmt == LLMIE_W_FP8 ? 3 * llmie_linear_fp8_workspace_bytes(c->max_batch, kmax) : 256);
+    offs[9] = k.take(c->wfmt == LLMIE_W_FP8 ? 3 * llmie_linear_fp8_workspace_bytes(c->max_batch, kmax, 0) : 256);
     offs[10] = k.take(packed_carve(c, packed_wf(c)).total + 256);   // packed weight images + x32 activations + slabs
+    offs[11] = k.take(engine_slab_floats(c, c->max_batch) * sizeof(float) + 256);   // split-K slabs of the row-major paths
     return k.off;
 }
 
 extern "C" size_t llmie_decoder_workspace_bytes(const llmie_decoder_config *cfg) {
     if (!config_ok(cfg)) return 0;
-    size_t offs[11];
+    size_t offs[12];
     return carve(cfg, offs);
 }
 
@@ -186,7 +216,7 @@ extern "C" llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg, 
         set_error("decoder_create: NULL layers/workspace");
         return nullptr;
     }
-    size_t offs[11];
+    size_t offs[12];
     const size_t need = carve(cfg, offs);
     if (workspace_bytes < need) {
         set_error("decoder_create: workspace too small (%zu < %zu)", workspace_bytes, need);
@@ -230,8 +260,10 @@ extern "C" llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg, 
     d->fp8_ws = base + offs[9];
     {
         const int kmax = cfg->inter_size > d->H ? cfg->inter_size : d->H;
-        d->fp8_ws_bytes = cfg->wfmt == LLMIE_W_FP8 ? llmie_linear_fp8_workspace_bytes(cfg->max_batch, kmax) : 0;
+        d->fp8_ws_bytes = cfg->wfmt == LLMIE_W_FP8 ? llmie_linear_fp8_workspace_bytes(cfg->max_batch, kmax, 0) : 0;
     }
+    d->slab_ws = SlabWs{reinterpret_cast<float *>(base + offs[11]), engine_slab_floats(cfg, cfg->max_batch)};
+    if (!d->slab_ws.floats) d->slab_ws.p = nullptr;
     d->pk_wf = packed_wf(cfg);
     if (d->pk_wf) {
         // one-time re-tiling of every matrix into the stream-friendly image (null stream, synchronous: create is not on the
@@ -342,33 +374,33 @@ static int engine_linear(const llmie_decoder *d, llmie_weight_format fmt, const 
     switch (fmt) {
         case LLMIE_W_F16:
             return linear_f16_nk((const half_t *)x, (const half_t *)w.data, (half_t *)y, M, K, N,
-                                 swiglu ? EPI_SWIGLU_ : EPI_NONE_, (const half_t *)bias, (const half_t *)residual,
+                                 swiglu ? EPI_SWIGLU_ : EPI_NONE_, (const half_t *)bias, (const half_t *)residual, d->slab_ws,
                                  as_stream(stream));
         case LLMIE_W_F32:
             if (swiglu) {
-                int rc = llmie_linear(x, w.data, d->gu, M, K, N, 1, bias, nullptr, LLMIE_F32, stream);
+                int rc = llmie_linear(x, w.data, d->gu, M, K, N, 1, bias, nullptr, LLMIE_F32, nullptr, 0, stream);
                 if (rc) return rc;
                 return llmie_silu_and_mul(d->gu, y, M, N / 2, LLMIE_F32, stream);
             }
-            return llmie_linear(x, w.data, y, M, K, N, 1, bias, residual, LLMIE_F32, stream);
+            return llmie_linear(x, w.data, y, M, K, N, 1, bias, residual, LLMIE_F32, nullptr, 0, stream);
         case LLMIE_W_INT8:
         case LLMIE_W_INT4: {
             const int bits = fmt == LLMIE_W_INT8 ? 8 : 4;
             // GEMV (M <= 8) and split-K MFMA (int8) paths take the SwiGLU epilogue directly
             int rc = linear_wq(bits, (const half_t *)x, w.data, (const half_t *)w.scale, (half_t *)y, M, K, N, d->cfg.int4_group,
                                swiglu ? EPI_SWIGLU_ : EPI_NONE_, (const half_t *)bias, (const half_t *)residual, nullptr, nullptr,
-                               0.f, as_stream(stream));
+                               0.f, d->slab_ws, as_stream(stream));
             return rc;
         }
         case LLMIE_W_FP8: {
             if (swiglu) {
-                int rc = llmie_linear_fp8(x, (const uint8_t *)w.data, (const float *)w.scale, d->gu, M, K, N, bias, nullptr,
-                                          d->fp8_ws, d->fp8_ws_bytes, stream);
+                int rc = linear_fp8((const half_t *)x, (const uint8_t *)w.data, (const float *)w.scale, (half_t *)d->gu, M, K, N,
+                                    (const half_t *)bias, nullptr, d->fp8_ws, d->fp8_ws_bytes, d->slab_ws, as_stream(stream));
                 if (rc) return rc;
                 return llmie_silu_and_mul(d->gu, y, M, N / 2, LLMIE_F16, stream);
             }
-            return llmie_linear_fp8(x, (const uint8_t *)w.data, (const float *)w.scale, y, M, K, N, bias, residual, d->fp8_ws,
-                                    d->fp8_ws_bytes, stream);
+            return linear_fp8((const half_t *)x, (const uint8_t *)w.data, (const float *)w.scale, (half_t *)y, M, K, N,
+                              (const half_t *)bias, (const half_t *)residual, d->fp8_ws, d->fp8_ws_bytes, d->slab_ws, as_stream(stream));
         }
         default:
             set_error("engine: weight format %d not supported by this build", (int)fmt);
@@ -444,8 +476,8 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
                     set_error("engine: fp8 projection K=%d at batch %d has no fused form", K, batch);
                     return LLMIE_ERR_UNSUPPORTED;
                 }
-                return llmie_linear_fp8(x, (const uint8_t *)w.data, (const float *)w.scale, y, batch, K, N, nullptr, residual,
-                                        dec->fp8_ws, dec->fp8_ws_bytes, stream);
+                return linear_fp8((const half_t *)x, (const uint8_t *)w.data, (const float *)w.scale, (half_t *)y, batch, K, N, nullptr,
+                                  (const half_t *)residual, dec->fp8_ws, dec->fp8_ws_bytes, dec->slab_ws, st);
             }
             if (wbits == 16) {
                 if (gamma)
@@ -453,11 +485,11 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
                                               (const half_t *)residual, (const half_t *)gamma, (const half_t *)pre_bias,
                                               c.rms_eps, st);
                 return linear_f16_nk((const half_t *)x, (const half_t *)w.data, (half_t *)y, batch, K, N, epi, nullptr,
-                                     (const half_t *)residual, st);
+                                     (const half_t *)residual, dec->slab_ws, st);
             }
             return linear_wq(wbits, (const half_t *)x, w.data, (const half_t *)w.scale, (half_t *)y, batch, K, N, c.int4_group,
                              epi, nullptr, (const half_t *)residual, (const half_t *)gamma, (const half_t *)pre_bias,
-                             c.rms_eps, st);
+                             c.rms_eps, dec->slab_ws, st);
         };
         for (int l = 0; l < c.num_layers; ++l) {
             const llmie_layer_weights &w = dec->layers[l];
@@ -547,23 +579,23 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
             const bool last = l + 1 == c.num_layers;
             const void *xin = fp8 ? static_cast<const void *>(xqA) : hh;
             SplitKSlabs sk;
-            TIMED(LLMIE_OP_QKV_GEMM, linear_splitk_partial(fmt, xin, w.qkv.data, batch, H, QKV, st, &sk, gs_of(w.qkv)));
+            TIMED(LLMIE_OP_QKV_GEMM, linear_splitk_partial(fmt, xin, w.qkv.data, batch, H, QKV, st, &sk, dec->slab_ws, gs_of(w.qkv)));
             const SlabScale qsc = scale_of(w.qkv, xsA);
             TIMED(LLMIE_OP_MHA, decoder_mha_rope(nullptr, w.qkv.bias, k_cache, v_cache, dec->mha, l, batch, c.head_num,
                                                  c.kv_head_num, c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws,
                                                  dec->attn_ws_bytes, dec->rope_table, c.rotary_dim, nullptr, dt, st, &sk, &qsc, kv8,
                                                  k_scale, v_scale, dec->page_table, dec->max_pages, dec->num_pages));
             if (fp8) TIMED(LLMIE_OP_O_GEMM, quantize_rows_fp8(mha, xqB, xsB, batch, H, st));
-            TIMED(LLMIE_OP_O_GEMM, linear_splitk_partial(fmt, fp8 ? static_cast<const void *>(xqB) : mha, w.o.data, batch, H, H, st, &sk, gs_of(w.o)));
+            TIMED(LLMIE_OP_O_GEMM, linear_splitk_partial(fmt, fp8 ? static_cast<const void *>(xqB) : mha, w.o.data, batch, H, H, st, &sk, dec->slab_ws, gs_of(w.o)));
             // self_decoder.cpp:92  h += resid; resid = h; h += o.bias; h = rmsnorm(h, ffn_gamma)
             TIMED(LLMIE_OP_FFN_NORM, splitk_rownorm(sk, scale_of(w.o, xsB), static_cast<const half_t *>(w.o.bias), resid,
                                                     static_cast<const half_t *>(w.ffn_norm_gamma), c.rms_eps,
                                                     fp8 ? nullptr : hh, xqA, xsA, st));
             // ffn.cpp:105-122  act = silu(h.Wg^T) * (h.Wu^T)
-            TIMED(LLMIE_OP_GATE_UP_SWIGLU, linear_splitk_partial(fmt, xin, w.gate_up.data, batch, H, 2 * I, st, &sk, gs_of(w.gate_up)));
+            TIMED(LLMIE_OP_GATE_UP_SWIGLU, linear_splitk_partial(fmt, xin, w.gate_up.data, batch, H, 2 * I, st, &sk, dec->slab_ws, gs_of(w.gate_up)));
             TIMED(LLMIE_OP_GATE_UP_SWIGLU, splitk_finalize(sk, scale_of(w.gate_up, xsA), act, EPI_SWIGLU_, nullptr, nullptr, st));
             if (fp8) TIMED(LLMIE_OP_DOWN_GEMM, quantize_rows_fp8(act, xqC, xsC, batch, I, st));
-            TIMED(LLMIE_OP_DOWN_GEMM, linear_splitk_partial(fmt, fp8 ? static_cast<const void *>(xqC) : act, w.down.data, batch, I, H, st, &sk, gs_of(w.down)));
+            TIMED(LLMIE_OP_DOWN_GEMM, linear_splitk_partial(fmt, fp8 ? static_cast<const void *>(xqC) : act, w.down.data, batch, I, H, st, &sk, dec->slab_ws, gs_of(w.down)));
             // ffn.cpp:132 + self_decoder.cpp:111 h = act.Wd^T + resid, then the next layer's resid = h; h = rmsnorm(h)
             const void *next_gamma = last ? nullptr : dec->layers[l + 1].attn_norm_gamma;
             TIMED(LLMIE_OP_ATTN_NORM, splitk_rownorm(sk, scale_of(w.down, xsC), nullptr, resid, static_cast<const half_t *>(next_gamma),
@@ -631,7 +663,7 @@ extern "C" int llmie_decoder_forward_paged(llmie_decoder *dec, const void *hidde
     return rc;
 }
 
-static size_t prefill_carve(const llmie_decoder_config *c, int T, int B, size_t *o /*[8]*/) {
+static size_t prefill_carve(const llmie_decoder_config *c, int T, int B, size_t *o /*[9]*/) {
     const size_t e = 2, H = static_cast<size_t>(c->head_num) * c->head_size;
     const size_t QKV = static_cast<size_t>(c->head_num + 2 * c->kv_head_num) * c->head_size, I = c->inter_size;
     Carve k;
@@ -643,13 +675,14 @@ static size_t prefill_carve(const llmie_decoder_config *c, int T, int B, size_t 
     o[5] = k.take(static_cast<size_t>(T) * sizeof(int32_t));        // padding offsets (by-product of the prefix kernel)
     o[6] = k.take(static_cast<size_t>(B + 1) * sizeof(int32_t));    // cum_seqlens
     // fp8 engines: per-token e4m3 image + scales of the activation matrix entering each projection
-    o[7] = k.take(c->wfmt == LLMIE_W_FP8 ? llmie_linear_fp8_workspace_bytes(T, static_cast<int>(I > H ? I : H)) : 256);
+    o[7] = k.take(c->wfmt == LLMIE_W_FP8 ? llmie_linear_fp8_workspace_bytes(T, static_cast<int>(I > H ? I : H), 0) : 256);
+    o[8] = k.take(engine_slab_floats(c, T < 192 ? T : 192) * sizeof(float) + 256);   // split-K slabs (short prefills; fp8 passes)
     return k.off;
 }
 
 extern "C" size_t llmie_decoder_prefill_workspace_bytes(const llmie_decoder_config *cfg, int max_tokens, int max_batch) {
     if (!config_ok(cfg) || max_tokens <= 0 || max_batch <= 0) return 0;
-    size_t o[8];
+    size_t o[9];
     return prefill_carve(cfg, max_tokens, max_batch, o);
 }
 
@@ -666,7 +699,7 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
     const bool fp8 = c.wfmt == LLMIE_W_FP8;
     if (c.dtype != LLMIE_F16 || (c.wfmt != LLMIE_W_F16 && !fp8) || c.head_size != 128)
         LLMIE_UNSUPPORTED("decoder_prefill: fp16 activations + fp16 or fp8 weights + head_size 128 only (use the per-kernel path)");
-    size_t o[8];
+    size_t o[9];
     const size_t need = prefill_carve(&c, num_tokens, batch, o);
     if (workspace_bytes < need || reinterpret_cast<uintptr_t>(workspace) % 256) {
         set_error("decoder_prefill: workspace too small or unaligned (%zu < %zu)", workspace_bytes, need);
@@ -687,13 +720,14 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
     }
     half_t *h = (half_t *)hidden_out;
     void *f8ws = base + o[7];
-    const size_t f8ws_bytes = fp8 ? llmie_linear_fp8_workspace_bytes(T, I > H ? I : H) : 0;
+    const size_t f8ws_bytes = fp8 ? llmie_linear_fp8_workspace_bytes(T, I > H ? I : H, 0) : 0;
+    const SlabWs slabs{reinterpret_cast<float *>(base + o[8]), engine_slab_floats(&c, T < 192 ? T : 192)};
     // y = x . W^T (+ residual) in the engine's weight format (fp8: per-token e4m3 activations, fp8 MFMA)
     auto proj = [&](const half_t *x, const llmie_matrix &w, half_t *y, int K, int N, const half_t *residual) -> int {
         if (fp8)
-            return llmie_linear_fp8(x, (const uint8_t *)w.data, (const float *)w.scale, y, T, K, N, nullptr, residual, f8ws,
-                                    f8ws_bytes, stream);
-        return linear_f16_nk(x, (const half_t *)w.data, y, T, K, N, EPI_NONE_, nullptr, residual, st);
+            return linear_fp8(x, (const uint8_t *)w.data, (const float *)w.scale, y, T, K, N, nullptr, residual, f8ws, f8ws_bytes,
+                              slabs, st);
+        return linear_f16_nk(x, (const half_t *)w.data, y, T, K, N, EPI_NONE_, nullptr, residual, slabs, st);
     };
     // context_decoder.cpp:70: exclusive prefix of the lengths (padding offsets are a by-product nobody needs here);
     // the prefix kernel takes [batch, max_q_len] with max_q_len = ceil(T / batch) rows worth of scratch -> use 1 row of T
@@ -709,20 +743,20 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
             const llmie_layer_weights &w = dec->layers[l];
             const bool last = l + 1 == c.num_layers;
             SplitKSlabs sk;
-            TIMED(LLMIE_OP_QKV_GEMM, linear_splitk_partial(16, h, w.qkv.data, T, H, QKV, st, &sk, nullptr));
+            TIMED(LLMIE_OP_QKV_GEMM, linear_splitk_partial(16, h, w.qkv.data, T, H, QKV, st, &sk, slabs));
             TIMED(LLMIE_OP_QKV_GEMM, splitk_finalize(sk, none, qkv, EPI_NONE_, nullptr, nullptr, st));
             TIMED(LLMIE_OP_MHA, prefill_attention_f16(qkv, (const half_t *)w.qkv.bias, k_cache, v_cache, attn, cum,
                                                       history_lengths, dec->rope_table, l, batch, T, max_q_len, c.head_num,
                                                       c.kv_head_num, c.head_size, c.max_seq_len, c.rotary_dim, st,
                                                       c.kv_fmt == LLMIE_KV_FP8, c.k_scale > 0.f ? c.k_scale : 1.f,
                                                       c.v_scale > 0.f ? c.v_scale : 1.f, dec->page_table, dec->max_pages, dec->num_pages));
-            TIMED(LLMIE_OP_O_GEMM, linear_splitk_partial(16, attn, w.o.data, T, H, H, st, &sk, nullptr));
+            TIMED(LLMIE_OP_O_GEMM, linear_splitk_partial(16, attn, w.o.data, T, H, H, st, &sk, slabs));
             // context_decoder.cpp: h += resid; resid = h; h += o.bias; h = rmsnorm(h, ffn_gamma)
             TIMED(LLMIE_OP_FFN_NORM, splitk_rownorm(sk, none, static_cast<const half_t *>(w.o.bias), resid,
                                                     static_cast<const half_t *>(w.ffn_norm_gamma), c.rms_eps, h, nullptr, nullptr, st));
-            TIMED(LLMIE_OP_GATE_UP_SWIGLU, linear_splitk_partial(16, h, w.gate_up.data, T, H, 2 * I, st, &sk, nullptr));
+            TIMED(LLMIE_OP_GATE_UP_SWIGLU, linear_splitk_partial(16, h, w.gate_up.data, T, H, 2 * I, st, &sk, slabs));
             TIMED(LLMIE_OP_GATE_UP_SWIGLU, splitk_finalize(sk, none, act, EPI_SWIGLU_, nullptr, nullptr, st));
-            TIMED(LLMIE_OP_DOWN_GEMM, linear_splitk_partial(16, act, w.down.data, T, I, H, st, &sk, nullptr));
+            TIMED(LLMIE_OP_DOWN_GEMM, linear_splitk_partial(16, act, w.down.data, T, I, H, st, &sk, slabs));
             // h = act.Wd^T + resid, then the next layer's resid = h; h = rmsnorm(h) (last layer: h stays un-normalised)
             const void *next_gamma = last ? nullptr : dec->layers[l + 1].attn_norm_gamma;
             TIMED(LLMIE_OP_ATTN_NORM, splitk_rownorm(sk, none, nullptr, resid, static_cast<const half_t *>(next_gamma), c.rms_eps, h,
@@ -767,7 +801,7 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
                                                                        LLMIE_F16, stream));
         // ffn.cpp:105-122: act = silu(h.Wg^T) * (h.Wu^T); SwiGLU fused into the projection's epilogue where a fused form exists
         if (!fp8 && (T <= 192 || gemm256_swiglu_fills(T, 2 * I))) {
-            TIMED(LLMIE_OP_GATE_UP_SWIGLU, linear_f16_nk(h, (const half_t *)w.gate_up.data, act, T, H, 2 * I, EPI_SWIGLU_, nullptr, nullptr, st));
+            TIMED(LLMIE_OP_GATE_UP_SWIGLU, linear_f16_nk(h, (const half_t *)w.gate_up.data, act, T, H, 2 * I, EPI_SWIGLU_, nullptr, nullptr, slabs, st));
         } else if (fp8 && gemm256_swiglu_fills(T, 2 * I) && H % 128 == 0 && reinterpret_cast<uintptr_t>(w.gate_up.data) % 16 == 0) {
             TIMED(LLMIE_OP_GATE_UP_SWIGLU, llmie_linear_fp8_swiglu(h, (const uint8_t *)w.gate_up.data, (const float *)w.gate_up.scale,
                                                                    act, T, H, 2 * I, f8ws, f8ws_bytes, stream));

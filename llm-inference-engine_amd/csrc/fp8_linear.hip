@@ -103,10 +103,14 @@ using namespace llmie;
 
 static size_t fp8_align(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
 
-extern "C" size_t llmie_linear_fp8_workspace_bytes(int M, int K) {
-    if (M <= 0 || K <= 0) return 0;
-    // quantised activations + per-token scales (the split-K slabs live in the library's own scratch)
+static size_t fp8_act_bytes(int M, int K) {   // quantised activations + per-token scales
     return fp8_align(static_cast<size_t>(M) * K) + fp8_align(static_cast<size_t>(M) * sizeof(float));
+}
+extern "C" size_t llmie_linear_fp8_workspace_bytes(int M, int K, int N) {
+    if (M <= 0 || K <= 0 || N < 0) return 0;
+    // quantised activations + per-token scales, then the fp32 slabs of the split-K form (8 < M, below the tiled GEMM's sizes);
+    // N = 0: the activation part only (llmie_linear_fp8_swiglu)
+    return fp8_act_bytes(M, K) + (N > 0 && M > 8 ? fp8_align(linear_splitk_ws_floats(WF_FP8, M, K, N) * sizeof(float)) : 0);
 }
 
 extern "C" int llmie_quantize_fp8(const void *w, uint8_t *wq, float *scale, int N, int K, llmie_stream stream) {
@@ -114,44 +118,62 @@ extern "C" int llmie_quantize_fp8(const void *w, uint8_t *wq, float *scale, int 
     return quantize_rows_fp8((const half_t *)w, wq, scale, N, K, as_stream(stream));
 }
 
-extern "C" int llmie_linear_fp8(const void *x, const uint8_t *w_fp8, const float *w_scale, void *y, int M, int K, int N,
-                                const void *bias, const void *residual, void *workspace, size_t workspace_bytes,
-                                llmie_stream stream) {
-    LLMIE_REQUIRE(x && w_fp8 && w_scale && y && workspace, "linear_fp8: NULL pointer");
-    LLMIE_REQUIRE(M > 0 && K > 0 && N > 0, "linear_fp8: bad shape");
-    const bool tiled = M > 8 && gemm256_fills(M, N) && K % 128 == 0 && N % 4 == 0 && reinterpret_cast<uintptr_t>(w_scale) % 16 == 0 &&
-                       (reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) % 8 == 0;
-    if ((!tiled && (K % 256 != 0 || K < 512)) || reinterpret_cast<uintptr_t>(w_fp8) % 16 || reinterpret_cast<uintptr_t>(workspace) % 256)
-        LLMIE_UNSUPPORTED("linear_fp8: needs K %% 256 == 0, K >= 512 (K %% 128 == 0 for prefill-sized M x N), 16-byte aligned "
-                          "weights, 256-byte aligned workspace");
-    if (workspace_bytes < llmie_linear_fp8_workspace_bytes(M, K)) {
-        set_error("linear_fp8: workspace too small");
+namespace llmie {
+static bool fp8_tiled(const void *w_scale, const void *bias, const void *residual, int M, int K, int N) {
+    return M > 8 && gemm256_fills(M, N) && K % 128 == 0 && N % 4 == 0 && reinterpret_cast<uintptr_t>(w_scale) % 16 == 0 &&
+           (reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) % 8 == 0;
+}
+// llmie_linear_fp8 with its two scratch areas apart: `act_ws` (>= llmie_linear_fp8_workspace_bytes(M, K, 0), 256-byte aligned)
+// receives the quantised activations, `slabs` the split-K partial sums (engine: one slab area serves every projection)
+int linear_fp8(const half_t *x, const uint8_t *w_fp8, const float *w_scale, half_t *y, int M, int K, int N, const half_t *bias,
+               const half_t *residual, void *act_ws, size_t act_ws_bytes, SlabWs slabs, hipStream_t st) {
+    const bool tiled = fp8_tiled(w_scale, bias, residual, M, K, N);
+    if ((!tiled && (K % 256 != 0 || K < 512)) || reinterpret_cast<uintptr_t>(w_fp8) % 16 || reinterpret_cast<uintptr_t>(act_ws) % 256) {
+        set_error("linear_fp8: needs K %% 256 == 0, K >= 512 (K %% 128 == 0 for prefill-sized M x N), 16-byte aligned weights, "
+                  "256-byte aligned workspace");
+        return LLMIE_ERR_UNSUPPORTED;
+    }
+    if (act_ws_bytes < fp8_act_bytes(M, K)) {
+        set_error("linear_fp8: workspace too small (%zu < %zu bytes)", act_ws_bytes, fp8_act_bytes(M, K));
         return LLMIE_ERR_WORKSPACE;
     }
-    hipStream_t st = as_stream(stream);
-    static const bool no_gemv = getenv("LLMIE_FP8_NO_GEMV") != nullptr;
-    if (!no_gemv && M <= 8 && ksplit_eligible(M, K, 8) && reinterpret_cast<uintptr_t>(x) % 16 == 0)
-        return linear_fp8_gemv((const half_t *)x, w_fp8, w_scale, (half_t *)y, M, K, N, EPI_NONE, (const half_t *)bias,
-                               (const half_t *)residual, nullptr, nullptr, 0.f, st);
-    uint8_t *xq = static_cast<uint8_t *>(workspace);
+    if (M <= 8 && ksplit_eligible(M, K, 8) && reinterpret_cast<uintptr_t>(x) % 16 == 0)
+        return linear_fp8_gemv(x, w_fp8, w_scale, y, M, K, N, EPI_NONE, bias, residual, nullptr, nullptr, 0.f, st);
+    uint8_t *xq = static_cast<uint8_t *>(act_ws);
     float *xscale = reinterpret_cast<float *>(xq + fp8_align(static_cast<size_t>(M) * K));
-    int rc = quantize_rows_fp8((const half_t *)x, xq, xscale, M, K, st);
+    int rc = quantize_rows_fp8(x, xq, xscale, M, K, st);
     if (rc) return rc;
     if (tiled) {
         // prefill-sized: MFMA-bound tiled GEMM on v_mfma_scale_f32_16x16x128_f8f6f4
-        gemm256_launch(true, xq, w_fp8, (half_t *)y, M, N, K, (const half_t *)bias, (const half_t *)residual, xscale, w_scale, st);
+        gemm256_launch(true, xq, w_fp8, y, M, N, K, bias, residual, xscale, w_scale, st);
         return launch_status("linear_fp8(gemm256)");
     }
     for (int m0 = 0; m0 < M; m0 += 128) {
         const int mc = M - m0 < 128 ? M - m0 : 128;
         SplitKSlabs sk;
-        rc = linear_splitk_partial(WF_FP8, xq + static_cast<size_t>(m0) * K, w_fp8, mc, K, N, st, &sk);
+        rc = linear_splitk_partial(WF_FP8, xq + static_cast<size_t>(m0) * K, w_fp8, mc, K, N, st, &sk, slabs);
         if (rc) return rc;
-        rc = splitk_finalize(sk, SlabScale{nullptr, w_scale, xscale + m0}, (half_t *)y + static_cast<size_t>(m0) * N, EPI_NONE,
-                             (const half_t *)bias, residual ? (const half_t *)residual + static_cast<size_t>(m0) * N : nullptr, st);
+        rc = splitk_finalize(sk, SlabScale{nullptr, w_scale, xscale + m0}, y + static_cast<size_t>(m0) * N, EPI_NONE, bias,
+                             residual ? residual + static_cast<size_t>(m0) * N : nullptr, st);
         if (rc) return rc;
     }
     return launch_status("linear_fp8");
+}
+}  // namespace llmie
+
+extern "C" int llmie_linear_fp8(const void *x, const uint8_t *w_fp8, const float *w_scale, void *y, int M, int K, int N,
+                                const void *bias, const void *residual, void *workspace, size_t workspace_bytes,
+                                llmie_stream stream) {
+    LLMIE_REQUIRE(x && w_fp8 && w_scale && y && workspace, "linear_fp8: NULL pointer");
+    LLMIE_REQUIRE(M > 0 && K > 0 && N > 0, "linear_fp8: bad shape");
+    const size_t act = fp8_act_bytes(M, K);
+    if (workspace_bytes < act) {
+        set_error("linear_fp8: workspace too small (%zu < %zu bytes)", workspace_bytes, llmie_linear_fp8_workspace_bytes(M, K, N));
+        return LLMIE_ERR_WORKSPACE;
+    }
+    const SlabWs slabs{reinterpret_cast<float *>(static_cast<char *>(workspace) + act), (workspace_bytes - act) / sizeof(float)};
+    return linear_fp8((const half_t *)x, w_fp8, w_scale, (half_t *)y, M, K, N, (const half_t *)bias, (const half_t *)residual,
+                      workspace, act, slabs, as_stream(stream));
 }
 
 extern "C" int llmie_linear_fp8_swiglu(const void *x, const uint8_t *w_fp8, const float *w_scale, void *y, int M, int K,
@@ -162,7 +184,7 @@ extern "C" int llmie_linear_fp8_swiglu(const void *x, const uint8_t *w_fp8, cons
         reinterpret_cast<uintptr_t>(workspace) % 256 || reinterpret_cast<uintptr_t>(y) % 8)
         LLMIE_UNSUPPORTED("linear_fp8_swiglu: prefill-sized shapes only (>= 192 tiles of 256 tokens x 128 columns, K %% 128 == 0, "
                           "two_inter %% 8 == 0); use llmie_linear_fp8 + llmie_silu_and_mul otherwise");
-    if (workspace_bytes < llmie_linear_fp8_workspace_bytes(M, K)) {
+    if (workspace_bytes < llmie_linear_fp8_workspace_bytes(M, K, 0)) {
         set_error("linear_fp8_swiglu: workspace too small");
         return LLMIE_ERR_WORKSPACE;
     }

@@ -175,22 +175,6 @@ static void launch_generic(const T *a, const T *b, T *c, int batch, int M, int N
 // fp16, W[N,K]: the decode / prefill projection path.  epi selects the fused epilogue; a non-null
 // `norm` fuses rmsnorm(x + pre_bias)*gamma in front of the projection (GEMV path only: returns
 // LLMIE_ERR_UNSUPPORTED otherwise so the caller can run the norm as its own kernel).
-// library-owned fp32 scratch for the split-K slabs: grows on first use (warm up once before hipGraph capture)
-static float *splitk_scratch(size_t floats) {
-    static float *buf = nullptr;
-    static size_t cap = 0;
-    if (floats > cap) {
-        // grow-only and geometric, and the outgrown buffer is NOT freed: a hipGraph captured earlier may still replay
-        // launches that point into it (doubling keeps the retained total below twice the final size)
-        const size_t want = floats > 2 * cap ? floats : 2 * cap;
-        float *bigger = nullptr;
-        if (hipMalloc(reinterpret_cast<void **>(&bigger), want * sizeof(float)) != hipSuccess) return nullptr;
-        buf = bigger;
-        cap = want;
-    }
-    return buf;
-}
-
 // y = sum over the KS slabs (* scales of the weight format) (+bias)(+residual) | SwiGLU over (n, N/2+n)
 static __global__ __launch_bounds__(256) void skinny_finalize_kernel(const float *__restrict__ slab, half_t *y, int M, int N, int KS,
                                                               const SlabScale scale, const half_t *__restrict__ bias,
@@ -218,46 +202,85 @@ static __global__ __launch_bounds__(256) void skinny_finalize_kernel(const float
     }
 }
 
-// split-K skinny MFMA path, first half: partial products of one pass (8 < M <= 128) into the library's fp32 slabs
-// [KS][M][N].  The slabs stay valid until the next split-K launch on the stream; the consumer (finalize kernel,
-// splitk_rownorm, or the decode attention reading q/k/v straight from the slabs) must be enqueued before it.
+// Split-K planning, shared by the launcher and by the workspace-size query (the slabs are CALLER-owned: nothing on the
+// compute path allocates, so a first call may already run under hipGraph capture).
+constexpr int kSplitKPassRows = 128;   // activation rows per pass (16 per MFMA tile)
+struct SplitKPlan {
+    int form;   // 0 = 64-weight-row skinny kernel, 1 = 128-row LDS-DMA kernel (gemm_mid.cuh), 2 = its 64-row form
+    int ks;     // K slices = slabs
+    int per;    // form 1 / 2: K tiles per slice; form 0: sub-blocks per slice
+    int wn;     // form 1 / 2: 64-row groups per workgroup (4 = 256 weight rows)
+    bool ok;
+};
+static SplitKPlan splitk_plan(int wbits, int M, int K, int N) {
+    SplitKPlan p{0, 1, 0, 2, false};
+    const int bk = wbits == 16 ? 128 : (wbits == 4 ? 512 : 256);  // k per sub-block (4 weight loads per lane)
+    if (wbits == 4 && (M > 64 || K % 256)) return p;
+    if (M < 1 || M > kSplitKPassRows || (wbits != 4 && K % bk) || K < 512 || (wbits != 16 && wbits != 8 && wbits != 4 && wbits != WF_FP8))
+        return p;
+    p.ok = true;
+    // 64 < M <= 128, fp16 or e4m3 operands: 128-row LDS-DMA kernel; 32 < M <= 64: its 64-row form (measured fp16 M=64:
+    // gate/up 55.6 -> 44.7 us, qkv 33.0 -> 29.8, down 29.2 -> 25.8 against the skinny kernel; about equal at M = 32)
+    const bool mid64 = M <= 64 && M >= 33;
+    if ((wbits == 16 || wbits == WF_FP8) && (M >= 65 || mid64) && K % 128 == 0 && N >= 128) {
+        const bool fp8 = wbits == WF_FP8;
+        p.form = mid64 ? 2 : 1;
+        p.wn = N >= 8192 ? 4 : 2;   // wide N: 256 weight rows per workgroup
+        const int mtiles = (N + 64 * p.wn - 1) / (64 * p.wn), KT = K / (fp8 ? 128 : 64);
+        int ks = 256 / mtiles;
+        ks = ks < 1 ? 1 : (ks > 8 ? 8 : ks);
+        if (ks > KT / 4) ks = KT / 4 > 0 ? KT / 4 : 1;
+        p.per = (KT + ks - 1) / ks;
+        p.ks = (KT + p.per - 1) / p.per;  // every slice non-empty
+        return p;
+    }
+    const int tiles = (N + 63) / 64, total_blocks = (K + bk - 1) / bk;
+    // K slices: enough workgroups to fill the chip (512), but >= 4 sub-blocks per slice (the weight ring depth) and as few
+    // slabs as possible (slab traffic = 2 * KS * M * N * 4 bytes)
+    int KS = 1;
+    const int min_blocks = wbits == 4 ? 1 : 4;  // int4 sub-blocks are 512 k wide: K = 4096 has only 8 of them
+    while (KS < 16 && tiles * KS < 512 && total_blocks / (KS * 2) >= min_blocks) KS *= 2;
+    p.ks = KS;
+    p.per = (total_blocks + KS - 1) / KS;
+    return p;
+}
+// fp32 floats of slab workspace a split-K projection of M rows needs (M > 128 runs in passes of 128 rows that reuse it);
+// 0 = this shape has no split-K form
+size_t linear_splitk_ws_floats(int wbits, int M, int K, int N) {
+    const int rows = wbits == 4 ? (M < 64 ? M : 64) : (M < kSplitKPassRows ? M : kSplitKPassRows);
+    if (rows < 1) return 0;
+    const SplitKPlan p = splitk_plan(wbits, rows, K, N);
+    return p.ok ? static_cast<size_t>(p.ks) * rows * N : 0;
+}
+
+// split-K skinny MFMA path, first half: partial products of one pass (M <= 128) into the caller's fp32 slabs [KS][M][N]
+// (`ws`, >= linear_splitk_ws_floats floats, 16-byte aligned).  The consumer (finalize kernel, splitk_rownorm, or the
+// decode attention reading q/k/v straight from the slabs) must be enqueued before the next launch that writes `ws`.
 int linear_splitk_partial(int wbits, const void *x, const void *W, int M, int K, int N, hipStream_t st, SplitKSlabs *out,
-                          const half_t *gscale) {
+                          SlabWs ws, const half_t *gscale) {
     // wbits: 16 = fp16 weights, 8 = int8 weights, 4 = int4 weights with group-128 scales `gscale` applied in the kernel (all
     // with fp16 activations), WF_FP8 = e4m3 weights and e4m3 activations
-    const int bk = wbits == 16 ? 128 : (wbits == 4 ? 512 : 256);  // k per sub-block (4 weight loads per lane)
-    if (wbits == 4 && (M > 64 || K % 256 || !gscale || reinterpret_cast<uintptr_t>(gscale) % 4)) {
+    const SplitKPlan p = splitk_plan(wbits, M, K, N);
+    if (wbits == 4 && (!gscale || reinterpret_cast<uintptr_t>(gscale) % 4 || !p.ok)) {
         set_error("linear(split-K int4): needs M <= 64 per pass, K %% 256 == 0, group-128 scales");
         return LLMIE_ERR_UNSUPPORTED;
     }
-    if (M < 1 || M > 128 || (wbits != 4 && K % bk) || K < 512 || (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) % 16 ||
-        (wbits != 16 && wbits != 8 && wbits != 4 && wbits != WF_FP8)) {
+    if (!p.ok || (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) % 16) {
         set_error("linear(split-K): unsupported shape M=%d K=%d (bits=%d)", M, K, wbits);
         return LLMIE_ERR_UNSUPPORTED;
     }
-    // 64 < M <= 128, fp16 or e4m3 operands: 128-row LDS-DMA kernel (gemm_mid.cuh)
-    static const int mid_min_m = env_int("LLMIE_MID_MIN_M", 65);
-    // 64-row form for 32 < M <= 64 (measured fp16 M=64: gate/up 55.6 -> 44.7 us, qkv 33.0 -> 29.8, down 29.2 -> 25.8 against the
-    // 64-weight-row skinny kernel; about equal at M = 32, which stays there)
-    static const int mid64_min_m = env_int("LLMIE_MID64_MIN_M", 33);
-    const bool mid64 = M <= 64 && M >= mid64_min_m;
-    if ((wbits == 16 || wbits == WF_FP8) && (M >= mid_min_m || mid64) && K % 128 == 0 && N >= 128) {
-        static const int mid_wgs = env_int("LLMIE_MID_WGS", 256), mid_maxks = env_int("LLMIE_MID_MAXKS", 8);
-        static const int mid_wide_n = env_int("LLMIE_MID_WIDE_N", 8192);  // N >= this: 256 weight rows per workgroup
-        const bool fp8 = wbits == WF_FP8;
-        const int wn = N >= mid_wide_n ? 4 : 2;
-        const int mtiles = (N + 64 * wn - 1) / (64 * wn), KT = K / (fp8 ? 128 : 64);
-        int ks = mid_wgs / mtiles;
-        ks = ks < 1 ? 1 : (ks > mid_maxks ? mid_maxks : ks);
-        if (ks > KT / 4) ks = KT / 4 > 0 ? KT / 4 : 1;
-        const int per = (KT + ks - 1) / ks;
-        ks = (KT + per - 1) / per;  // every slice non-empty
-        float *mslab = splitk_scratch(static_cast<size_t>(ks) * M * N);
-        if (!mslab) {
-            set_error("linear: split-K scratch allocation failed");
-            return LLMIE_ERR_WORKSPACE;
-        }
-        static bool attr_set = false;
+    const size_t need = static_cast<size_t>(p.ks) * M * N;
+    if (!ws.p || ws.floats < need || reinterpret_cast<uintptr_t>(ws.p) % 16) {
+        set_error("linear(split-K): slab workspace too small or misaligned (%zu < %zu bytes); size it with "
+                  "llmie_linear_workspace_bytes()", ws.p ? ws.floats * sizeof(float) : static_cast<size_t>(0), need * sizeof(float));
+        return LLMIE_ERR_WORKSPACE;
+    }
+    if (p.form != 0) {
+        const bool fp8 = wbits == WF_FP8, mid64 = p.form == 2;
+        const int wn = p.wn, ks = p.ks, per = p.per;
+        const int mtiles = (N + 64 * wn - 1) / (64 * wn);
+        float *mslab = ws.p;
+    static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<false, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 16384);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<true, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 16384);
@@ -295,19 +318,8 @@ int linear_splitk_partial(int wbits, const void *x, const void *W, int M, int K,
         out->N = N;
         return launch_status("linear(split-K 128-row)");
     }
-    const int tiles = (N + 63) / 64, total_blocks = (K + bk - 1) / bk;
-    static const int target = env_int("LLMIE_SPLITK_TARGET_WGS", 512);
-    // K slices: enough workgroups to fill the chip, but >= 4 sub-blocks per slice (the weight ring depth) and as few
-    // slabs as possible (slab traffic = 2 * KS * M * N * 4 bytes)
-    int KS = 1;
-    const int min_blocks = wbits == 4 ? 1 : 4;  // int4 sub-blocks are 512 k wide: K = 4096 has only 8 of them
-    while (KS < 16 && tiles * KS < target && total_blocks / (KS * 2) >= min_blocks) KS *= 2;
-    const int spp = (total_blocks + KS - 1) / KS;
-    float *slab = splitk_scratch(static_cast<size_t>(KS) * M * N);
-    if (!slab) {
-        set_error("linear: split-K scratch allocation failed");
-        return LLMIE_ERR_WORKSPACE;
-    }
+    const int tiles = (N + 63) / 64, KS = p.ks, spp = p.per;
+    float *slab = ws.p;
     const int mt = (M + 15) / 16;
     const dim3 grid(tiles * KS);
 #define LLMIE_SK(MT_)                                                                                          \
@@ -342,15 +354,14 @@ int linear_splitk_partial(int wbits, const void *x, const void *W, int M, int K,
 
 // split-K skinny MFMA path: 8 < M (any M, 128 rows of x per pass); wbits 16 or 8
 int linear_splitk(int wbits, const half_t *x, const void *W, const half_t *scale, half_t *y, int M, int K, int N, int epi,
-                  const half_t *bias, const half_t *residual, hipStream_t st) {
+                  const half_t *bias, const half_t *residual, SlabWs ws, hipStream_t st) {
     // wbits 8: `scale` = per-row fp16 scales applied by the finalize; wbits 4: `scale` = group-128 scales applied in the kernel
-    static const int mpass_env = env_int("LLMIE_SPLITK_PASS_M", 128);  // activation rows per pass (16 per MFMA tile, <= 128)
-    const int mpass = wbits == 4 ? 64 : mpass_env;
+    const int mpass = wbits == 4 ? 64 : kSplitKPassRows;
     const int out_n = epi == EPI_SWIGLU ? N / 2 : N;
     for (int m0 = 0; m0 < M; m0 += mpass) {
         const int mc = M - m0 < mpass ? M - m0 : mpass;
         SplitKSlabs sk;
-        const int rc = linear_splitk_partial(wbits, x + static_cast<size_t>(m0) * K, W, mc, K, N, st, &sk, wbits == 4 ? scale : nullptr);
+        const int rc = linear_splitk_partial(wbits, x + static_cast<size_t>(m0) * K, W, mc, K, N, st, &sk, ws, wbits == 4 ? scale : nullptr);
         if (rc) return rc;
         const size_t total = static_cast<size_t>(mc) * out_n;
         int fgrid = static_cast<int>((total + 255) / 256);
@@ -609,16 +620,16 @@ void gemm256_launch(bool fp8, const void *x, const void *W, half_t *y, int M, in
 }
 
 int linear_f16_nk(const half_t *x, const half_t *W, half_t *y, int M, int K, int N, int epi,
-                  const half_t *bias, const half_t *residual, hipStream_t st) {
+                  const half_t *bias, const half_t *residual, SlabWs ws, hipStream_t st) {
     const bool aligned = (K % 8 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) % 16 == 0);
     bool done = false;
     if (gemv_f16_eligible(M, K, x, W)) {
         const GemvArgs a{x, W, y, K, N, bias, residual, nullptr, nullptr, 0.f, epi, 0, nullptr, 0};
         done = dispatch_gemv(M, a, st);
     }
-    static const int splitk_max_m = env_int("LLMIE_SPLITK_MAX_M", 192);
-    if (!done && aligned && M <= splitk_max_m && K % 128 == 0 && K >= 512 && decode_gemm_mode() != 3)
-        return linear_splitk(16, x, W, nullptr, y, M, K, N, epi, bias, residual, st);
+    // decode / short-prefill batches: split-K over the caller's slabs (without a workspace: the non-split kernels below)
+    if (!done && ws.p && aligned && M <= 192 && K % 128 == 0 && K >= 512)
+        return linear_splitk(16, x, W, nullptr, y, M, K, N, epi, bias, residual, ws, st);
     if (!done && aligned && M <= 64 && K % 32 == 0 && (epi != EPI_SWIGLU || (N / 2) % 16 == 0)) {
         done = (epi == EPI_SWIGLU) ? dispatch_skinny<EPI_SWIGLU>(M, x, W, y, K, N, bias, residual, st)
                                    : dispatch_skinny<EPI_NONE>(M, x, W, y, K, N, bias, residual, st);
@@ -628,7 +639,7 @@ int linear_f16_nk(const half_t *x, const half_t *W, half_t *y, int M, int K, int
         return launch_status("linear(gemm256 SwiGLU)");
     }
     if (!done && epi == EPI_SWIGLU) {
-        set_error("linear: fused SwiGLU epilogue needs M<=64, K%%32==0, (N/2)%%16==0 (M=%d K=%d N=%d)", M, K, N);
+        set_error("linear: fused SwiGLU epilogue without a split-K workspace needs M<=64, K%%32==0, (N/2)%%16==0 (M=%d K=%d N=%d)", M, K, N);
         return LLMIE_ERR_UNSUPPORTED;
     }
     if (!done && aligned && K % 64 == 0 && reinterpret_cast<uintptr_t>(y) % 8 == 0) {
@@ -652,16 +663,38 @@ int linear_f16_nk(const half_t *x, const half_t *W, half_t *y, int M, int K, int
 
 using namespace llmie;
 
+// fp32 slab scratch of the split-K forms for this shape (the counterpart of the workspace the reference's cublasWrapper owns)
+extern "C" size_t llmie_linear_workspace_bytes(llmie_weight_format fmt, int M, int K, int N) {
+    if (M <= 0 || K <= 0 || N <= 0) return 0;
+    int wbits;
+    switch (fmt) {
+        case LLMIE_W_F16: wbits = 16; break;
+        case LLMIE_W_INT8: wbits = 8; break;
+        case LLMIE_W_INT4: wbits = 4; break;
+        case LLMIE_W_FP8: wbits = WF_FP8; break;
+        default: return 0;
+    }
+    if (fmt == LLMIE_W_F16 && M > 192) return 0;   // prefill-sized fp16: tiled kernels, no slabs
+    return linear_splitk_ws_floats(wbits, M, K, N) * sizeof(float);
+}
+
+static bool slab_ws_of(void *workspace, size_t bytes, SlabWs *out) {
+    *out = SlabWs{static_cast<float *>(workspace), bytes / sizeof(float)};
+    return !workspace || reinterpret_cast<uintptr_t>(workspace) % 16 == 0;
+}
+
 extern "C" int llmie_linear(const void *x, const void *w, void *y, int M, int K, int N, int trans_b,
-                            const void *bias, const void *residual, llmie_dtype dtype,
-                            llmie_stream stream) {
+                            const void *bias, const void *residual, llmie_dtype dtype, void *workspace,
+                            size_t workspace_bytes, llmie_stream stream) {
     LLMIE_REQUIRE(x && w && y, "linear: NULL pointer");
     LLMIE_REQUIRE(M > 0 && K > 0 && N > 0, "linear: bad shape M=%d K=%d N=%d", M, K, N);
+    SlabWs ws;
+    LLMIE_REQUIRE(slab_ws_of(workspace, workspace_bytes, &ws), "linear: workspace must be 16-byte aligned");
     hipStream_t st = as_stream(stream);
     if (dtype == LLMIE_F16) {
         if (trans_b)
             return linear_f16_nk((const half_t *)x, (const half_t *)w, (half_t *)y, M, K, N, EPI_NONE,
-                                 (const half_t *)bias, (const half_t *)residual, st);
+                                 (const half_t *)bias, (const half_t *)residual, ws, st);
         launch_generic<half_t>((const half_t *)x, (const half_t *)w, (half_t *)y, 1, M, N, K, false,
                                (const half_t *)bias, (const half_t *)residual, st);
         return launch_status("linear");
@@ -675,12 +708,14 @@ extern "C" int llmie_linear(const void *x, const void *w, void *y, int M, int K,
 }
 
 extern "C" int llmie_linear_swiglu(const void *x, const void *w, void *y, int M, int K, int two_inter,
-                                   llmie_dtype dtype, llmie_stream stream) {
+                                   llmie_dtype dtype, void *workspace, size_t workspace_bytes, llmie_stream stream) {
     LLMIE_REQUIRE(x && w && y, "linear_swiglu: NULL pointer");
     LLMIE_REQUIRE(M > 0 && K > 0 && two_inter > 0 && two_inter % 2 == 0, "linear_swiglu: bad shape");
     if (dtype != LLMIE_F16) LLMIE_UNSUPPORTED("linear_swiglu: fp16 only (dtype %d)", (int)dtype);
+    SlabWs ws;
+    LLMIE_REQUIRE(slab_ws_of(workspace, workspace_bytes, &ws), "linear_swiglu: workspace must be 16-byte aligned");
     return linear_f16_nk((const half_t *)x, (const half_t *)w, (half_t *)y, M, K, two_inter, EPI_SWIGLU, nullptr,
-                         nullptr, as_stream(stream));
+                         nullptr, ws, as_stream(stream));
 }
 
 extern "C" int llmie_batched_gemm(const void *a, const void *b, void *c, int batch, int m, int n, int k,

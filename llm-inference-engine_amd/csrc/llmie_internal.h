@@ -8,8 +8,16 @@ enum : int { EPI_NONE_ = 0, EPI_SWIGLU_ = 1 };
 
 // fp16 activations, fp16 W[N,K]; epi = 0 plain (bias/residual optional), 1 = SwiGLU over row
 // pairs (i, N/2+i) writing y[M, N/2].  Defined in linear.hip.
+// Caller-owned fp32 scratch for split-K slabs (nothing on the compute path allocates).  p == nullptr: the split-K forms are
+// not available to the call (fp16 falls back to its non-split kernels; shapes that only have a split-K form fail with
+// LLMIE_ERR_WORKSPACE); p != nullptr but too small / not 16-byte aligned: LLMIE_ERR_WORKSPACE.
+struct SlabWs {
+    float *p;
+    size_t floats;
+};
+size_t linear_splitk_ws_floats(int wbits, int M, int K, int N);   // 0 = the shape has no split-K form
 int linear_f16_nk(const half_t *x, const half_t *W, half_t *y, int M, int K, int N, int epi,
-                  const half_t *bias, const half_t *residual, hipStream_t st);
+                  const half_t *bias, const half_t *residual, SlabWs ws, hipStream_t st);
 
 // same with rmsnorm(x + pre_bias) * gamma fused in front (GEMV path only; LLMIE_ERR_UNSUPPORTED otherwise)
 bool gemv_f16_eligible(int M, int K, const void *x, const void *W);
@@ -17,14 +25,14 @@ int linear_f16_nk_norm(const half_t *x, const half_t *W, half_t *y, int M, int K
                        const half_t *residual, const half_t *gamma, const half_t *pre_bias, float eps, hipStream_t st);
 
 // split-K skinny MFMA GEMM (fp16 or int8 weights), any M processed 64 tokens per pass; epi may be SwiGLU; linear.hip
-// partial products of a split-K projection: fp32 slabs [KS][M][N] in library-owned scratch (see linear.hip)
+// partial products of a split-K projection: fp32 slabs [KS][M][N] in the caller's SlabWs
 struct SplitKSlabs {
     float *slab;
     int KS, M, N;
 };
 enum : int { WF_FP8 = 108 };  // wbits code of e4m3 weights + e4m3 activations (16 / 8 = fp16 / int8 weights, fp16 activations)
 int linear_splitk_partial(int wbits, const void *x, const void *W, int M, int K, int N, hipStream_t st, SplitKSlabs *out,
-                          const half_t *gscale = nullptr /* wbits 4: group-128 scales [N, K/128], applied in the kernel */);
+                          SlabWs ws, const half_t *gscale = nullptr /* wbits 4: group-128 scales [N, K/128], applied in the kernel */);
 int splitk_finalize(const SplitKSlabs &sk, const SlabScale &sc, half_t *y, int epi, const half_t *bias, const half_t *residual,
                     hipStream_t st);
 bool splitk_rownorm_eligible(int N);
@@ -38,7 +46,7 @@ int rmsnorm_quant_f16(const half_t *x, half_t *resid, const half_t *bias, const 
 // per-token e4m3 quantisation of fp16 rows (scale amax/448); fp8_linear.hip
 int quantize_rows_fp8(const half_t *x, uint8_t *xq, float *xscale, int M, int K, hipStream_t st);
 int linear_splitk(int wbits, const half_t *x, const void *W, const half_t *scale, half_t *y, int M, int K, int N, int epi,
-                  const half_t *bias, const half_t *residual, hipStream_t st);
+                  const half_t *bias, const half_t *residual, SlabWs ws, hipStream_t st);
 // 256 x 256 LDS-DMA tiled GEMM (gemm256.cuh; K % 64 == 0 fp16, K % 128 == 0 fp8; 16-byte aligned operands); linear.hip
 bool gemm256_fills(int M, int N);
 void gemm256_launch(bool fp8, const void *x, const void *W, half_t *y, int M, int N, int K, const half_t *bias,
@@ -55,10 +63,13 @@ bool gemv_fp8_launch(int M, const GemvArgs &a, hipStream_t st);
 int linear_fp8_gemv(const half_t *x, const uint8_t *wq, const float *wscale, half_t *y, int M, int K, int N, int epi,
                     const half_t *bias, const half_t *residual, const half_t *gamma, const half_t *pre_bias, float eps,
                     hipStream_t st);
+// llmie_linear_fp8 with the activation scratch and the split-K slabs as separate areas; fp8_linear.hip
+int linear_fp8(const half_t *x, const uint8_t *w_fp8, const float *w_scale, half_t *y, int M, int K, int N, const half_t *bias,
+               const half_t *residual, void *act_ws, size_t act_ws_bytes, SlabWs slabs, hipStream_t st);
 // weight-only int8/int4 linear with optional fused norm prologue / SwiGLU epilogue (quant_linear.hip)
 int linear_wq(int wbits, const half_t *x, const void *wq, const half_t *scale, half_t *y, int M, int K, int N, int group,
               int epi, const half_t *bias, const half_t *residual, const half_t *gamma, const half_t *pre_bias, float eps,
-              hipStream_t st);
+              SlabWs ws, hipStream_t st);
 
 // ---- packed-weight batch-decode projections (pk_gemm.cuh / pk_linear.hip): 1 <= M <= 32 rows on tile-packed weight images ----
 enum : int { PKF_F16 = 16, PKF_I8 = 8, PKF_I4 = 4, PKF_FP8 = 108 };                 // = PK_F16 ... of pk_gemm.cuh

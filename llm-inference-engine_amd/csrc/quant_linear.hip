@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64) void quantize_w4_kernel(const half_t *__restric
 
 int linear_wq(int wbits, const half_t *x, const void *wq, const half_t *scale, half_t *y, int M, int K, int N, int group,
               int epi, const half_t *bias, const half_t *residual, const half_t *gamma, const half_t *pre_bias, float eps,
-              hipStream_t st) {
+              SlabWs ws, hipStream_t st) {
     const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wq) |
                            reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(pre_bias)) % 16 == 0) &&
                          (static_cast<size_t>(K) * wbits / 8) % 16 == 0;
@@ -146,8 +146,8 @@ int linear_wq(int wbits, const half_t *x, const void *wq, const half_t *scale, h
         const GemvArgs a{x, wq, y, K, N, bias, residual, gamma, pre_bias, eps, epi, gamma ? 1 : 0, scale, group};
         if (gemv_q_launch(wbits, M, a, st)) return launch_status("linear_wq");
     }
-    if (aligned && wbits == 4 && group == 128 && K % 256 == 0 && K >= 512 && M > 8 && !gamma && !getenv("LLMIE_NO_SPLITK"))
-        return linear_splitk(4, x, wq, scale, y, M, K, N, epi, bias, residual, st);  // MFMA path, group scales in the kernel
+    if (aligned && wbits == 4 && group == 128 && K % 256 == 0 && K >= 512 && M > 8 && !gamma && ws.p)
+        return linear_splitk(4, x, wq, scale, y, M, K, N, epi, bias, residual, ws, st);  // MFMA path, group scales in the kernel
     if (aligned && wbits == 4) {
         // other int4 shapes: batches beyond the GEMV's register budget run as row chunks of the largest eligible
         // size (the weights are streamed once per chunk -- correct for any batch, bandwidth-efficient only for small ones)
@@ -172,8 +172,8 @@ int linear_wq(int wbits, const half_t *x, const void *wq, const half_t *scale, h
         set_error("linear_wq: fused norm only on the GEMV path (M=%d K=%d bits=%d)", M, K, wbits);
         return LLMIE_ERR_UNSUPPORTED;
     }
-    if (wbits == 8 && aligned && K % 256 == 0 && K >= 512 && !getenv("LLMIE_NO_SPLITK"))
-        return linear_splitk(8, x, wq, scale, y, M, K, N, epi, bias, residual, st);
+    if (wbits == 8 && aligned && K % 256 == 0 && K >= 512 && ws.p)
+        return linear_splitk(8, x, wq, scale, y, M, K, N, epi, bias, residual, ws, st);
     if (epi != EPI_NONE) {
         set_error("linear_wq: fused SwiGLU needs the GEMV or split-K path (M=%d K=%d bits=%d)", M, K, wbits);
         return LLMIE_ERR_UNSUPPORTED;
@@ -190,8 +190,8 @@ int linear_wq(int wbits, const half_t *x, const void *wq, const half_t *scale, h
         }
         return launch_status("linear_w8a16");
     }
-    set_error("linear_wq: unsupported shape M=%d K=%d N=%d bits=%d (int8: M<=64, K%%64==0; int4: M<=8 on the GEMV path)", M, K,
-              N, wbits);
+    set_error("linear_wq: unsupported shape M=%d K=%d N=%d bits=%d without a split-K workspace (int8: M<=64, K%%64==0; int4: "
+              "M<=8 on the GEMV path); size one with llmie_linear_workspace_bytes()", M, K, N, wbits);
     return LLMIE_ERR_UNSUPPORTED;
 }
 
@@ -200,20 +200,26 @@ int linear_wq(int wbits, const half_t *x, const void *wq, const half_t *scale, h
 using namespace llmie;
 
 extern "C" int llmie_linear_w8a16(const void *x, const int8_t *wq, const void *scale, void *y, int M, int K, int N,
-                                  const void *bias, const void *residual, llmie_stream stream) {
+                                  const void *bias, const void *residual, void *workspace, size_t workspace_bytes,
+                                  llmie_stream stream) {
     LLMIE_REQUIRE(x && wq && scale && y, "linear_w8a16: NULL pointer");
     LLMIE_REQUIRE(M > 0 && K > 0 && N > 0, "linear_w8a16: bad shape");
+    LLMIE_REQUIRE(reinterpret_cast<uintptr_t>(workspace) % 16 == 0, "linear_w8a16: workspace must be 16-byte aligned");
     return linear_wq(8, (const half_t *)x, wq, (const half_t *)scale, (half_t *)y, M, K, N, 0, EPI_NONE,
-                     (const half_t *)bias, (const half_t *)residual, nullptr, nullptr, 0.f, as_stream(stream));
+                     (const half_t *)bias, (const half_t *)residual, nullptr, nullptr, 0.f,
+                     SlabWs{static_cast<float *>(workspace), workspace_bytes / sizeof(float)}, as_stream(stream));
 }
 
 extern "C" int llmie_linear_w4a16(const void *x, const uint8_t *wq, const void *scale, void *y, int M, int K, int N,
-                                  int group, const void *bias, const void *residual, llmie_stream stream) {
+                                  int group, const void *bias, const void *residual, void *workspace, size_t workspace_bytes,
+                                  llmie_stream stream) {
     LLMIE_REQUIRE(x && wq && scale && y, "linear_w4a16: NULL pointer");
     LLMIE_REQUIRE(M > 0 && K > 0 && N > 0, "linear_w4a16: bad shape");
     LLMIE_REQUIRE(group > 0 && group % 32 == 0 && K % group == 0, "linear_w4a16: group must be a multiple of 32 dividing K");
+    LLMIE_REQUIRE(reinterpret_cast<uintptr_t>(workspace) % 16 == 0, "linear_w4a16: workspace must be 16-byte aligned");
     return linear_wq(4, (const half_t *)x, wq, (const half_t *)scale, (half_t *)y, M, K, N, group, EPI_NONE,
-                     (const half_t *)bias, (const half_t *)residual, nullptr, nullptr, 0.f, as_stream(stream));
+                     (const half_t *)bias, (const half_t *)residual, nullptr, nullptr, 0.f,
+                     SlabWs{static_cast<float *>(workspace), workspace_bytes / sizeof(float)}, as_stream(stream));
 }
 
 extern "C" int llmie_quantize_w8(const void *w, int8_t *wq, void *scale, int N, int K, llmie_stream stream) {

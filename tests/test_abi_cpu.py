@@ -46,7 +46,7 @@ def test_invalid_arguments_fail_loudly(lib):
     # NULL pointers / bad shapes are rejected on the host with a message (reference: LLM_CHECK throws)
     assert lib.llmie_rmsnorm(None, None, None, 1e-6, 4, 8, 0, None) == -1
     assert b"rmsnorm" in lib.llmie_last_error()
-    assert lib.llmie_linear(None, None, None, 1, 1, 1, 1, None, None, 1, None) == -1
+    assert lib.llmie_linear(None, None, None, 1, 1, 1, 1, None, None, 1, None, 0, None) == -1
     assert lib.llmie_add_residual(None, None, 0, 0, 0, None) == -1
     one = C.c_void_p(16)  # never dereferenced: shape check fails first
     assert lib.llmie_topk(one, one, one, one, one, 1, 100, 64, 8, 0, None) == -1

@@ -217,7 +217,7 @@ def test_linear_packed_fp8_matches_e4m3_emulation(llmie):
     llmie.linear_packed(llmie.W_FP8, _d(x), packed, ws, y, N)
     # reference: the row-major fp8 linear of this library on the same quantised weights (itself pinned against the numpy e4m3
     # emulation in tests/test_quant_gpu.py)
-    work = torch.empty(llmie.linear_fp8_workspace_bytes(M, K), dtype=torch.uint8, device=DEV)
+    work = torch.empty(llmie.linear_fp8_workspace_bytes(M, K, N), dtype=torch.uint8, device=DEV)
     y2 = torch.empty((M, N), dtype=F16, device=DEV)
     llmie.linear_fp8(_d(x), wq, ws, y2, work)
     err = (y.float() - y2.float()).abs().cpu().numpy()

@@ -196,7 +196,7 @@ def test_linear_fp8(llmie, M, K, N):
     wq = torch.empty((N, K), dtype=torch.uint8, device=DEV)
     ws = torch.empty(N, dtype=torch.float32, device=DEV)
     llmie.quantize_fp8(wd, wq, ws)
-    work = torch.empty(llmie.linear_fp8_workspace_bytes(M, K), dtype=torch.uint8, device=DEV)
+    work = torch.empty(llmie.linear_fp8_workspace_bytes(M, K, N), dtype=torch.uint8, device=DEV)
     y = torch.empty((M, N), dtype=F16, device=DEV)
     llmie.linear_fp8(torch.from_numpy(x).to(DEV).to(F16), wq, ws, y, work)
     # oracle: fp32 GEMM over the de-quantised operands (device weight codes; numpy e4m3 rounding of the activations)

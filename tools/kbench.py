@@ -41,7 +41,7 @@ if "prefill" in sys.argv:
             for w in W:
                 q = torch.empty((N, K), dtype=torch.uint8, device=dev); sc = torch.empty(N, dtype=torch.float32, device=dev)
                 llmie.quantize_fp8(w, q, sc); Q.append((q, sc))
-            work = torch.empty(llmie.linear_fp8_workspace_bytes(M, K), dtype=torch.uint8, device=dev)
+            work = torch.empty(llmie.linear_fp8_workspace_bytes(M, K, N), dtype=torch.uint8, device=dev)
             t = timeit(lambda i: llmie.linear_fp8(x, Q[i % 4][0], Q[i % 4][1], y, work), n=8)
             print("M=%d %-8s fp8 %8.1f us  %6.1f TFLOP/s (incl. activation quantisation)" % (M, name, t, 2.0 * M * N * K / t / 1e6))
             del W, Q
