@@ -166,6 +166,17 @@ int llmie_decoder_mha_rope(const void *qkv, const void *qkv_bias, void *k_cache,
                            void *workspace, size_t workspace_bytes, const void *rope_table,
                            int rotary_dim, int32_t *tickets, llmie_dtype dtype, llmie_stream stream);
 
+/* Ragged batch (continuous batching; no reference counterpart: the reference's decode step shares ONE `step` across the batch,
+ * decoder_self_attention.cu:211-270 / self_decoder.cpp:69): ctx_len_dev[b] = tokens of sequence b INCLUDING this step's; the RoPE
+ * position, the append slot and the attention span are per sequence.  A value outside [1, max_seq_len] leaves that sequence's
+ * cache and output untouched.  block_table (nullable) = paged cache, see llmie_decoder_forward_paged.  Row b equals the row a
+ * batch-1 call at step ctx_len[b] produces, bit for bit (same kernels, same chunking). */
+int llmie_decoder_mha_ragged(const void *qkv, const void *qkv_bias, void *k_cache, void *v_cache, void *out, int layer,
+                             int batch, int head_num, int kv_head_num, int head_size, int max_seq_len,
+                             const int32_t *ctx_len_dev, void *workspace, size_t workspace_bytes, const void *rope_table,
+                             int rotary_dim, const int32_t *block_table, int max_pages, int num_pages,
+                             llmie_dtype dtype, llmie_stream stream);
+
 /* replaces launchConcatKVCache         src/kernels/concat_past_kv.cu:44-89  (one call = K or V) */
 int llmie_concat_kv(const void *src, void *cache, const int32_t *cur_len,
                     const int32_t *history_len, int layer, int batch, int kv_head_num,
@@ -345,6 +356,14 @@ int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, void *hidde
 int llmie_decoder_forward_paged(llmie_decoder *dec, const void *hidden_in, void *hidden_out, void *k_pool, void *v_pool,
                                 const int32_t *block_table, int max_pages, int num_pages, int batch, int step,
                                 const int32_t *step_dev, llmie_stream stream);
+/* Ragged batch (continuous batching; the reference steps a whole batch at ONE position, self_decoder.cpp:69-119): sequence b
+ * is at context length ctx_len_dev[b] (device int32 [batch], including this step's token).  Only the attention launch differs
+ * (RoPE position, append slot, span per sequence); row b is what llmie_decoder_forward at step ctx_len[b] gives that row. */
+int llmie_decoder_forward_ragged(llmie_decoder *dec, const void *hidden_in, void *hidden_out, void *k_cache, void *v_cache,
+                                 int batch, const int32_t *ctx_len_dev, llmie_stream stream);
+int llmie_decoder_forward_paged_ragged(llmie_decoder *dec, const void *hidden_in, void *hidden_out, void *k_pool, void *v_pool,
+                                       const int32_t *block_table, int max_pages, int num_pages, int batch,
+                                       const int32_t *ctx_len_dev, llmie_stream stream);
 int llmie_decoder_prefill_paged(llmie_decoder *dec, const void *hidden_in, void *hidden_out, void *k_pool, void *v_pool,
                                 const int32_t *block_table, int max_pages, int num_pages, const int32_t *input_lengths,
                                 const int32_t *history_lengths, int batch, int num_tokens, int max_q_len, void *workspace,

@@ -81,6 +81,9 @@ _SIGS = {
     "llmie_decoder_create": [_vp, _vp, _vp, _sz],
     "llmie_decoder_destroy": [_vp],
     "llmie_decoder_forward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
+    "llmie_decoder_forward_ragged": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "llmie_decoder_forward_paged_ragged": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "llmie_decoder_mha_ragged": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _i, _vp, _i, _i, _i, _vp],
     "llmie_decoder_prefill_workspace_bytes": [_vp, _i, _i],
     "llmie_decoder_prefill": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp],
     "llmie_lm_head_sample": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp,
@@ -273,6 +276,20 @@ def decoder_mha(qkv, qkv_bias, k_cache, v_cache, out, layer, head_num, kv_head_n
     return out
 
 
+def decoder_mha_ragged(qkv, qkv_bias, k_cache, v_cache, out, layer, head_num, kv_head_num, ctx_len, workspace, rope_table,
+                       rotary_dim, max_seq_len, block_table=None):
+    """ragged batch: ctx_len device int32 [batch]; caches dense [L, batch, kvh, max_seq, hs] or (block_table given) page pools
+    [L, num_pages, kvh, 128, hs]"""
+    batch, hs = qkv.shape[0], qkv.shape[-1]
+    _check(lib().llmie_decoder_mha_ragged(_p(qkv), _p(qkv_bias), _p(k_cache), _p(v_cache), _p(out), layer, batch, head_num,
+                                          kv_head_num, hs, max_seq_len, _p(ctx_len), _p(workspace),
+                                          workspace.numel() * workspace.element_size(), _p(rope_table), rotary_dim,
+                                          _p(block_table), block_table.shape[1] if block_table is not None else 0,
+                                          k_cache.shape[1] if block_table is not None else 0, _dt(qkv), _st()),
+           "decoder_mha_ragged")
+    return out
+
+
 def decoder_mha_rope(qkv, qkv_bias, k_cache, v_cache, out, layer, head_num, kv_head_num, step, workspace, rope_table,
                      rotary_dim, tickets, step_dev=None):
     bs, _, hs = qkv.shape
@@ -384,6 +401,18 @@ class Decoder:
     def forward(self, hidden_in, hidden_out, k_cache, v_cache, step, step_dev=None):
         _check(lib().llmie_decoder_forward(self.handle, _p(hidden_in), _p(hidden_out), _p(k_cache), _p(v_cache),
                                            hidden_in.shape[0], step, _p(step_dev), _st()), "decoder_forward")
+        return hidden_out
+
+    def forward_ragged(self, hidden_in, hidden_out, k_cache, v_cache, ctx_len):
+        """ctx_len: device int32 [batch], context length of each sequence including this step's token"""
+        _check(lib().llmie_decoder_forward_ragged(self.handle, _p(hidden_in), _p(hidden_out), _p(k_cache), _p(v_cache),
+                                                  hidden_in.shape[0], _p(ctx_len), _st()), "decoder_forward_ragged")
+        return hidden_out
+
+    def forward_paged_ragged(self, hidden_in, hidden_out, k_pool, v_pool, block_table, ctx_len):
+        _check(lib().llmie_decoder_forward_paged_ragged(self.handle, _p(hidden_in), _p(hidden_out), _p(k_pool), _p(v_pool),
+                                                        _p(block_table), block_table.shape[1], k_pool.shape[1],
+                                                        hidden_in.shape[0], _p(ctx_len), _st()), "decoder_forward_paged_ragged")
         return hidden_out
 
     def forward_paged(self, hidden_in, hidden_out, k_pool, v_pool, block_table, step, step_dev=None):

@@ -99,7 +99,22 @@ constexpr int KV_PAGE = 128;
 struct PagedKv {
     const int32_t *table;
     int max_pages;
+    // (two more launch-wide layout facts ride along with the cache layout)
+    int step_stride;   // 0: one position for the whole batch (step / *step_dev); 1: ragged batch, step_dev[b] = context length
+                       // of sequence b INCLUDING this step's token
+    int out_x32;       // the output rows go to the x32 activation image of the packed projections (<= 32 sequences)
 };
+// position of sequence b (a value outside [1, max_seq_len] makes every workgroup of that sequence return without touching
+// the caches or the output: a corrupt device-resident position must not become an out-of-bounds append)
+__device__ __forceinline__ int seq_step(const int32_t *step_dev, int step_arg, int stride, int b, int max_seq_len) {
+    const int s = step_dev ? step_dev[static_cast<size_t>(b) * stride] : step_arg;
+    return (s >= 1 && s <= max_seq_len) ? s : 0;
+}
+// element index of (sequence b, feature k) in the attention output: row-major [batch][width] or the x32 image
+__device__ __forceinline__ size_t attn_out_index(int x32, int b, int k, int width) {
+    if (!x32) return static_cast<size_t>(b) * width + k;
+    return (static_cast<size_t>(k >> 5) * 2 + (b >> 4)) * 512 + ((k & 31) >> 3) * 128 + (b & 15) * 8 + (k & 7);
+}
 
 // Merge of the per-split (m, l, o[d]) partials of one (batch, head) for output dim d: 16 splits per round,
 // every load of a round issued before the first use.  Shared by the stand-alone merge kernel and by the
@@ -158,10 +173,10 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
     constexpr int NT = kAttnWaves * 64;
     static_assert(HS % N == 0 && LPT >= 1 && LPT <= 64 && (LPT & (LPT - 1)) == 0, "head size");
 
-    const int step = step_dev ? *step_dev : step_arg;
     const int split = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+    const int step = seq_step(step_dev, step_arg, pg.step_stride, b, max_seq_len);
     const int t0 = split * CHUNK;
-    if (t0 >= step) return;  // whole workgroup exits together
+    if (t0 >= step) return;  // whole workgroup exits together (also: invalid position)
     const int t_end = min(step, t0 + CHUNK);
     const int nsplits = (step + CHUNK - 1) / CHUNK;
     const int batch = gridDim.z;
@@ -467,7 +482,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
         }
         const int h = g * REP + r;
         if (nsplits == 1) {
-            out[(static_cast<size_t>(b) * head_num + h) * HS + d] = from_f32<T>(o / (L + 1e-6f));
+            out[attn_out_index(pg.out_x32, b, h * HS + d, head_num * HS)] = from_f32<T>(o / (L + 1e-6f));
         } else {
             float *p = part + ((static_cast<size_t>(b) * head_num + h) * max_splits + split) * (HS + 2);
             if (wt_merge) {  // write-through (agent-scope) stores: visible at the memory side once vmcnt drains
@@ -518,7 +533,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
                 const int h = g * REP + r;
                 const float *p = part + (static_cast<size_t>(b) * head_num + h) * max_splits * stride;
                 const float v = wt_merge ? merge_splits<true>(p, nsplits, stride, d) : merge_splits<false>(p, nsplits, stride, d);
-                out[(static_cast<size_t>(b) * head_num + h) * HS + d] = from_f32<T>(v);
+                out[attn_out_index(pg.out_x32, b, h * HS + d, head_num * HS)] = from_f32<T>(v);
             }
         }
     }
@@ -532,15 +547,15 @@ __global__ __launch_bounds__(256) void decode_attn_combine_kernel(const float *_
                                                                   T *__restrict__ out, int head_num,
                                                                   int head_size, int chunk, int step_arg,
                                                                   const int32_t *__restrict__ step_dev,
-                                                                  int max_splits) {
-    const int step = step_dev ? *step_dev : step_arg;
-    const int nsplits = (step + chunk - 1) / chunk;
-    if (nsplits <= 1) return;  // the split kernel already wrote the final output
+                                                                  int max_splits, int step_stride, int max_seq_len, int out_x32) {
     const int h = blockIdx.x, b = blockIdx.y;
+    const int step = seq_step(step_dev, step_arg, step_stride, b, max_seq_len);
+    const int nsplits = (step + chunk - 1) / chunk;
+    if (nsplits <= 1) return;  // the split kernel already wrote the final output (or: invalid position)
     const size_t stride = static_cast<size_t>(head_size) + 2;
     const float *p = part + (static_cast<size_t>(b) * head_num + h) * max_splits * stride;
     for (int d = threadIdx.x; d < head_size; d += blockDim.x)
-        out[(static_cast<size_t>(b) * head_num + h) * head_size + d] = from_f32<T>(merge_splits<false>(p, nsplits, stride, d));
+        out[attn_out_index(out_x32, b, h * head_size + d, head_num * head_size)] = from_f32<T>(merge_splits<false>(p, nsplits, stride, d));
 }
 
 // Any head size / GQA ratio (e.g. the reference unit test's hs=4): one workgroup per (b, q-head),
@@ -552,8 +567,9 @@ __global__ __launch_bounds__(256) void decode_attn_generic_kernel(
     const int32_t *__restrict__ step_dev) {
     extern __shared__ float logits[];  // [step]
     __shared__ float red[4];
-    const int step = step_dev ? *step_dev : step_arg;
     const int h = blockIdx.x, b = blockIdx.y;
+    const int step = seq_step(step_dev, step_arg, 0, b, max_seq_len);
+    if (step == 0) return;   // invalid device-resident position
     const int rep = head_num / kv_head_num, g = h / rep;
     const int qkv_heads = head_num + 2 * kv_head_num;
     const T *row = qkv + static_cast<size_t>(b) * qkv_heads * head_size;
@@ -630,7 +646,8 @@ static void launch_split(const T *qkv, const T *bias, KT *kc, KT *vc, float *par
     if (splits > 1 && !tickets) {
         dim3 cgrid(head_num, batch);
         decode_attn_combine_kernel<T><<<cgrid, HS < 64 ? 64 : (HS > 256 ? 256 : HS), 0, st>>>(part, out, head_num, HS, CHUNK,
-                                                                                              step, step_dev, max_splits_ws);
+                                                                                              step, step_dev, max_splits_ws, pg.step_stride,
+                                                                                              max_seq_len, pg.out_x32);
     }
 }
 
@@ -654,7 +671,7 @@ template <typename T>
 static int decoder_mha_impl(const T *qkv, const T *bias, T *k_cache, T *v_cache, T *out, int layer, int batch,
                             int head_num, int kv_head_num, int head_size, int max_seq_len, int step,
                             const int32_t *step_dev, void *workspace, size_t workspace_bytes, const float2 *rope,
-                            int rot_dim, int32_t *tickets, const QkvSlabs &qs, hipStream_t st, PagedKv pg = PagedKv{nullptr, 0},
+                            int rot_dim, int32_t *tickets, const QkvSlabs &qs, hipStream_t st, PagedKv pg = PagedKv{nullptr, 0, 0, 0},
                             int num_pages = 0) {
     const size_t layer_off = pg.table ? static_cast<size_t>(layer) * num_pages * kv_head_num * KV_PAGE * head_size
                                       : static_cast<size_t>(layer) * batch * kv_head_num * max_seq_len * head_size;
@@ -692,6 +709,10 @@ static int decoder_mha_impl(const T *qkv, const T *bias, T *k_cache, T *v_cache,
     }
     if (!done && rope) {
         set_error("decoder_mha: fused RoPE needs head_size in {32,64,128,256} and head_num/kv_head_num in {1,2,4,8}");
+        return LLMIE_ERR_UNSUPPORTED;
+    }
+    if (!done && (pg.step_stride || pg.out_x32)) {
+        set_error("decoder_mha: ragged batches / x32 output need head_size in {32,64,128,256} and head_num/kv_head_num in {1,2,4,8}");
         return LLMIE_ERR_UNSUPPORTED;
     }
     if (!done) {
@@ -744,8 +765,17 @@ int decoder_mha_rope(const void *qkv, const void *qkv_bias, void *k_cache, void 
                      int head_num, int kv_head_num, int head_size, int max_seq_len, int step, const int32_t *step_dev,
                      void *workspace, size_t workspace_bytes, const float2 *rope, int rot_dim, int32_t *tickets,
                      llmie_dtype dtype, hipStream_t st, const SplitKSlabs *qkv_slabs, const SlabScale *qkv_scale, int kv_fp8,
-                     float k_scale, float v_scale, const int32_t *block_table, int max_pages, int num_pages) {
-    const PagedKv pg{block_table, max_pages};
+                     float k_scale, float v_scale, const int32_t *block_table, int max_pages, int num_pages, int ragged,
+                     int out_x32) {
+    const PagedKv pg{block_table, max_pages, ragged ? 1 : 0, out_x32 ? 1 : 0};
+    if (ragged && !step_dev) {
+        set_error("decoder_mha: a ragged batch needs the device array of context lengths");
+        return LLMIE_ERR_INVALID_ARG;
+    }
+    if (out_x32 && (batch > 32 || dtype != LLMIE_F16)) {
+        set_error("decoder_mha: the x32 output image holds at most 32 fp16 rows");
+        return LLMIE_ERR_UNSUPPORTED;
+    }
     if (block_table && (max_pages <= 0 || num_pages <= 0 || static_cast<long long>(max_pages) * KV_PAGE < max_seq_len)) {
         set_error("decoder_mha: paged KV cache needs max_pages * %d >= max_seq_len and num_pages > 0", KV_PAGE);
         return LLMIE_ERR_UNSUPPORTED;
@@ -831,4 +861,22 @@ extern "C" int llmie_decoder_mha_rope(const void *qkv, const void *qkv_bias, voi
     return decoder_mha_rope(qkv, qkv_bias, k_cache, v_cache, out, layer, batch, head_num, kv_head_num, head_size,
                             max_seq_len, step, step_dev, workspace, workspace_bytes,
                             static_cast<const float2 *>(rope_table), rotary_dim, tickets, dtype, as_stream(stream));
+}
+
+// Ragged batch: RoPE position, append slot and attention span per sequence (ctx_len_dev[b] includes this step's token);
+// block_table != NULL: paged cache pools.  Same kernels as llmie_decoder_mha_rope.
+extern "C" int llmie_decoder_mha_ragged(const void *qkv, const void *qkv_bias, void *k_cache, void *v_cache, void *out, int layer,
+                                        int batch, int head_num, int kv_head_num, int head_size, int max_seq_len,
+                                        const int32_t *ctx_len_dev, void *workspace, size_t workspace_bytes, const void *rope_table,
+                                        int rotary_dim, const int32_t *block_table, int max_pages, int num_pages,
+                                        llmie_dtype dtype, llmie_stream stream) {
+    LLMIE_REQUIRE(qkv && k_cache && v_cache && out && ctx_len_dev, "decoder_mha_ragged: NULL pointer");
+    LLMIE_REQUIRE(layer >= 0 && batch > 0 && head_num > 0 && kv_head_num > 0 && head_size > 0 && max_seq_len > 0,
+                  "decoder_mha_ragged: bad shape");
+    LLMIE_REQUIRE(head_num % kv_head_num == 0, "decoder_mha_ragged: kv_head_num must divide head_num");
+    LLMIE_REQUIRE(!rope_table || (rotary_dim > 0 && rotary_dim % 2 == 0), "decoder_mha_ragged: bad rotary_dim");
+    if (dtype != LLMIE_F32 && dtype != LLMIE_F16) LLMIE_UNSUPPORTED("decoder_mha_ragged: dtype %d", (int)dtype);
+    return decoder_mha_rope(qkv, qkv_bias, k_cache, v_cache, out, layer, batch, head_num, kv_head_num, head_size, max_seq_len, -1,
+                            ctx_len_dev, workspace, workspace_bytes, static_cast<const float2 *>(rope_table), rotary_dim, nullptr,
+                            dtype, as_stream(stream), nullptr, nullptr, 0, 1.f, 1.f, block_table, max_pages, num_pages, 1, 0);
 }

@@ -32,6 +32,7 @@ struct llmie_decoder {
     void *fp8_ws;        // LLMIE_W_FP8 engines: activation quantisation + split-K scratch of llmie_linear_fp8
     size_t fp8_ws_bytes;
     SlabWs slab_ws;      // fp32 slabs of the split-K projections (batch path, row-major engines)
+    int ragged = 0;      // set for the duration of a *_ragged forward: step_dev is the per-sequence context-length array
     int32_t *tickets;    // [max_batch, kv_head_num] arrival counters of the in-launch attention merge (zero between launches)
     // packed-weight batch path (gemv_max < batch <= 32): tile-packed images of the four matrices of every layer (built once at
     // create time into the caller's workspace: the MI355X's 288 GB buy a second, stream-friendly copy of the weights), the
@@ -42,6 +43,7 @@ struct llmie_decoder {
     std::vector<PackedLayer> packed;
     int pk_wf = 0;                    // PKF_* of the engine's weight format, 0 = no packed path
     half_t *hx = nullptr, *actx = nullptr;   // x32 images: residual stream [32, H], SwiGLU output [32, I]
+    half_t *mhax = nullptr;                  // x32 image of the attention output [32, H]
     float *pk_slab = nullptr;
     size_t pk_slab_floats = 0;
     // paged KV cache of the current llmie_decoder_forward_paged call (null: dense caches)
@@ -125,7 +127,7 @@ static int packed_wf(const llmie_decoder_config *c) {
     return wf;
 }
 struct PackedCarve {
-    size_t per_layer[4], layer_bytes, hx, actx, slab, total;
+    size_t per_layer[4], layer_bytes, hx, actx, mhax, slab, total;
 };
 static PackedCarve packed_carve(const llmie_decoder_config *c, int wf) {
     PackedCarve p{};
@@ -138,6 +140,7 @@ static PackedCarve packed_carve(const llmie_decoder_config *c, int wf) {
     p.layer_bytes = p.per_layer[0] + p.per_layer[1] + p.per_layer[2] + p.per_layer[3];
     p.hx = align_up(static_cast<size_t>(H) * 64);
     p.actx = align_up(static_cast<size_t>(I) * 64);
+    p.mhax = p.hx;
     const int m = c->max_batch < 32 ? c->max_batch : 32;
     size_t sl = 0;
     for (int mm = 1; mm <= m; ++mm) {
@@ -145,7 +148,7 @@ static PackedCarve packed_carve(const llmie_decoder_config *c, int wf) {
         sl = f > sl ? f : sl;
     }
     p.slab = align_up(sl * sizeof(float) + 16);
-    p.total = p.layer_bytes * c->num_layers + p.hx + p.actx + p.slab;
+    p.total = p.layer_bytes * c->num_layers + p.hx + p.actx + p.mhax + p.slab;
     return p;
 }
 
@@ -286,9 +289,10 @@ extern "C" llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg, 
         unsigned char *tail = pb + pc.layer_bytes * cfg->num_layers;
         d->hx = reinterpret_cast<half_t *>(tail);
         d->actx = reinterpret_cast<half_t *>(tail + pc.hx);
-        d->pk_slab = reinterpret_cast<float *>(tail + pc.hx + pc.actx);
+        d->mhax = reinterpret_cast<half_t *>(tail + pc.hx + pc.actx);
+        d->pk_slab = reinterpret_cast<float *>(tail + pc.hx + pc.actx + pc.mhax);
         d->pk_slab_floats = (pc.slab - 16) / sizeof(float);
-        if (prc != LLMIE_OK || hipMemset(tail, 0, pc.hx + pc.actx) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        if (prc != LLMIE_OK || hipMemset(tail, 0, pc.hx + pc.actx + pc.mhax) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
             set_error("decoder_create: packing the weights for the batch path failed");
             delete d;
             return nullptr;
@@ -498,7 +502,8 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
                                                  c.kv_head_num, c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws,
                                                  dec->attn_ws_bytes, dec->rope_table, c.rotary_dim,
                                                  (merge_in_kernel && !kv8 && !dec->page_table) ? dec->tickets : nullptr, dt, st, nullptr,
-                                                 nullptr, kv8, k_scale, v_scale, dec->page_table, dec->max_pages, dec->num_pages));
+                                                 nullptr, kv8, k_scale, v_scale, dec->page_table, dec->max_pages, dec->num_pages,
+                                                 dec->ragged));
             TIMED(LLMIE_OP_O_GEMM, lin(dec->mha, w.o, h, H, H, EPI_NONE_, h, nullptr, nullptr));
             TIMED(LLMIE_OP_GATE_UP_SWIGLU, lin(h, w.gate_up, dec->act, H, 2 * I, EPI_SWIGLU_, nullptr, w.ffn_norm_gamma, w.o.bias));
             TIMED(LLMIE_OP_DOWN_GEMM, lin(dec->act, w.down, h, I, H, EPI_NONE_, h, nullptr, nullptr));
@@ -520,7 +525,7 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
         hipStream_t st = as_stream(stream);
         const int wf = dec->pk_wf;
         half_t *hh = static_cast<half_t *>(h);
-        half_t *mha = reinterpret_cast<half_t *>(dec->mha), *qkvb = reinterpret_cast<half_t *>(dec->qkv);
+        half_t *qkvb = reinterpret_cast<half_t *>(dec->qkv);
         for (int l = 0; l < c.num_layers; ++l) {
             const llmie_layer_weights &w = dec->layers[l];
             const llmie_decoder::PackedLayer &pw = dec->packed[l];
@@ -528,11 +533,11 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
             // layer 0 reads the caller's row-major hidden state; from its output projection on the residual stream lives in hx
             TIMED(LLMIE_OP_QKV_GEMM, pk_linear(wf, first ? hh : dec->hx, pw.qkv, w.qkv.scale, qkvb, batch, H, QKV, PKE_PLAIN, first ? 0 : PKX_X,
                                                nullptr, static_cast<const half_t *>(w.attn_norm_gamma), nullptr, c.rms_eps, nullptr, 0, st));
-            TIMED(LLMIE_OP_MHA, decoder_mha_rope(dec->qkv, w.qkv.bias, k_cache, v_cache, dec->mha, l, batch, c.head_num, c.kv_head_num,
+            TIMED(LLMIE_OP_MHA, decoder_mha_rope(dec->qkv, w.qkv.bias, k_cache, v_cache, dec->mhax, l, batch, c.head_num, c.kv_head_num,
                                                  c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws, dec->attn_ws_bytes,
                                                  dec->rope_table, c.rotary_dim, nullptr, dt, st, nullptr, nullptr, kv8, k_scale, v_scale,
-                                                 dec->page_table, dec->max_pages, dec->num_pages));
-            TIMED(LLMIE_OP_O_GEMM, pk_linear(wf, mha, pw.o, w.o.scale, dec->hx, batch, H, H, PKE_PLAIN, PKX_Y | (first ? 0 : PKX_RES),
+                                                 dec->page_table, dec->max_pages, dec->num_pages, dec->ragged, 1));
+            TIMED(LLMIE_OP_O_GEMM, pk_linear(wf, dec->mhax, pw.o, w.o.scale, dec->hx, batch, H, H, PKE_PLAIN, PKX_X | PKX_Y | (first ? 0 : PKX_RES),
                                              first ? hh : dec->hx, nullptr, nullptr, 0.f, nullptr, 0, st));
             TIMED(LLMIE_OP_GATE_UP_SWIGLU, pk_linear(wf, dec->hx, pw.gate_up, w.gate_up.scale, dec->actx, batch, H, 2 * I, PKE_SWIGLU, PKX_X | PKX_Y,
                                                      nullptr, static_cast<const half_t *>(w.ffn_norm_gamma), static_cast<const half_t *>(w.o.bias),
@@ -584,7 +589,7 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
             TIMED(LLMIE_OP_MHA, decoder_mha_rope(nullptr, w.qkv.bias, k_cache, v_cache, dec->mha, l, batch, c.head_num,
                                                  c.kv_head_num, c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws,
                                                  dec->attn_ws_bytes, dec->rope_table, c.rotary_dim, nullptr, dt, st, &sk, &qsc, kv8,
-                                                 k_scale, v_scale, dec->page_table, dec->max_pages, dec->num_pages));
+                                                 k_scale, v_scale, dec->page_table, dec->max_pages, dec->num_pages, dec->ragged));
             if (fp8) TIMED(LLMIE_OP_O_GEMM, quantize_rows_fp8(mha, xqB, xsB, batch, H, st));
             TIMED(LLMIE_OP_O_GEMM, linear_splitk_partial(fmt, fp8 ? static_cast<const void *>(xqB) : mha, w.o.data, batch, H, H, st, &sk, dec->slab_ws, gs_of(w.o)));
             // self_decoder.cpp:92  h += resid; resid = h; h += o.bias; h = rmsnorm(h, ffn_gamma)
@@ -624,8 +629,12 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
             TIMED(LLMIE_OP_MHA, decoder_mha_rope(dec->qkv, w.qkv.bias, k_cache, v_cache, dec->mha, l, batch, c.head_num,
                                                  c.kv_head_num, c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws,
                                                  dec->attn_ws_bytes, dec->rope_table, c.rotary_dim, nullptr, dt,
-                                                 as_stream(stream)));
+                                                 as_stream(stream), nullptr, nullptr, 0, 1.f, 1.f, nullptr, 0, 0, dec->ragged));
         } else {
+            if (dec->ragged) {
+                set_error("decoder_forward_ragged: needs head_size in {32,64,128,256} and head_num/kv_head_num in {1,2,4,8}");
+                return LLMIE_ERR_UNSUPPORTED;
+            }
             // :100 RoPE at position step-1
             TIMED(LLMIE_OP_ROPE, llmie_rope_decode(dec->qkv, batch, c.head_num, c.kv_head_num, c.head_size, step, step_dev,
                                                    c.rotary_dim, c.rotary_base, dt, stream));
@@ -645,6 +654,28 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
         TIMED(LLMIE_OP_DOWN_GEMM, engine_linear(dec, c.wfmt, dec->act, w.down, h, batch, I, H, false, dec->resid, false, stream));
     }
     return LLMIE_OK;
+}
+
+// Ragged batch (continuous batching): ctx_len_dev[b] = context length of sequence b including this step's token.  Every
+// projection is row-wise, so only the attention launch sees the difference (RoPE position, append slot, span per sequence).
+extern "C" int llmie_decoder_forward_ragged(llmie_decoder *dec, const void *hidden_in, void *hidden_out, void *k_cache,
+                                            void *v_cache, int batch, const int32_t *ctx_len_dev, llmie_stream stream) {
+    LLMIE_REQUIRE(dec && ctx_len_dev, "decoder_forward_ragged: NULL pointer");
+    dec->ragged = 1;
+    const int rc = llmie_decoder_forward(dec, hidden_in, hidden_out, k_cache, v_cache, batch, -1, ctx_len_dev, stream);
+    dec->ragged = 0;
+    return rc;
+}
+
+extern "C" int llmie_decoder_forward_paged_ragged(llmie_decoder *dec, const void *hidden_in, void *hidden_out, void *k_pool,
+                                                  void *v_pool, const int32_t *block_table, int max_pages, int num_pages, int batch,
+                                                  const int32_t *ctx_len_dev, llmie_stream stream) {
+    LLMIE_REQUIRE(dec && ctx_len_dev, "decoder_forward_paged_ragged: NULL pointer");
+    dec->ragged = 1;
+    const int rc = llmie_decoder_forward_paged(dec, hidden_in, hidden_out, k_pool, v_pool, block_table, max_pages, num_pages, batch,
+                                               -1, ctx_len_dev, stream);
+    dec->ragged = 0;
+    return rc;
 }
 
 extern "C" int llmie_decoder_forward_paged(llmie_decoder *dec, const void *hidden_in, void *hidden_out, void *k_pool, void *v_pool,

@@ -95,7 +95,9 @@ int decoder_mha_rope(const void *qkv, const void *qkv_bias, void *k_cache, void 
                      int kv_fp8 = 0 /* caches are e4m3 bytes, stored = e4m3(x / scale) */, float k_scale = 1.f, float v_scale = 1.f,
                      const int32_t *block_table = nullptr /* paged cache: [batch, max_pages] pool pages of 128 tokens; the cache
                                                              pointers are then pools [L, num_pages, kvh, 128, hs] */,
-                     int max_pages = 0, int num_pages = 0);
+                     int max_pages = 0, int num_pages = 0,
+                     int ragged = 0 /* step_dev is an array: step_dev[b] = context length of sequence b incl. this token */,
+                     int out_x32 = 0 /* out is the x32 activation image (batch <= 32) instead of row-major [batch, H] */);
 
 // prefill attention (RoPE + KV append + flash attention) on the packed QKV buffer; prefill.hip
 int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, void *k_cache, void *v_cache, half_t *out,
