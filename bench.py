@@ -160,10 +160,58 @@ def cpu_baseline(cfg, ctx, budget_s=25.0):
         reps += 1
     tl, tm = sorted(t_layer)[len(t_layer) // 2], sorted(t_lm)[len(t_lm) // 2]
     step_s = cfg["num_layers"] * tl + tm
-    return dict(value=1.0 / step_s, unit="tokens/s", cores=int(orc.lib().orc_num_threads()), kind="port",
-                sample="oracle (fp32 C restatement of the reference kernels, OpenMP) decode step at ctx %d: "
-                       "1 of %d layers timed (median of %d runs: %.3f s) x%d + LM head/top-k/sampling (%.3f s)"
-                       % (ctx, cfg["num_layers"], reps, tl, cfg["num_layers"], tm))
+    threads = int(orc.lib().orc_num_threads())
+    out = dict(value=1.0 / step_s, unit="tokens/s", cores=threads, kind="port",
+               sample="config C: oracle (fp32 C restatement of the reference kernels, OpenMP) decode step at ctx %d: "
+                      "1 of %d layers timed (median of %d runs: %.3f s) x%d + LM head/top-k/sampling (%.3f s)"
+                      % (ctx, cfg["num_layers"], reps, tl, cfg["num_layers"], tm))
+    # the same layer on ONE thread (BASELINE.md section 4 asks for 1 thread and all threads)
+    orc.lib().orc_set_num_threads(1)
+    t0 = time.perf_counter()
+    orc.self_decoder(ocfg, [layer], x, kc, vc, ctx)
+    t1 = time.perf_counter()
+    hn, _ = orc.rmsnorm(x, np.ones(H, np.float32), 1e-5)
+    orc.topk(orc.linear(hn, lm), 4)
+    t2 = time.perf_counter()
+    out["one_thread"] = dict(value=1.0 / (cfg["num_layers"] * (t1 - t0) + (t2 - t1)), unit="tokens/s", cores=1,
+                             sample="config C on one thread: 1 layer (%.3f s) x%d + LM head (%.3f s), single run"
+                                    % (t1 - t0, cfg["num_layers"], t2 - t1))
+    orc.lib().orc_set_num_threads(threads)
+    del layer, lm, kc, vc
+
+    # configs A and B: one layer, prefill of `seq` tokens then one decode step
+    def small(name, nh_, hs_, I_, seq, note):
+        H_, QKV_ = nh_ * hs_, 3 * nh_ * hs_
+        r = np.random.default_rng(1234)
+        u = lambda n, k: r.uniform(-0.05, 0.05, (n, k)).astype(np.float32)
+        lw = dict(attn_norm=np.ones(H_, np.float32), qkv=u(QKV_, H_), qkv_bias=None, o=u(H_, H_), o_bias=None,
+                  ffn_norm=np.ones(H_, np.float32), gate_up=u(2 * I_, H_), down=u(H_, I_))
+        c = dict(head_num=nh_, kv_head_num=nh_, head_size=hs_, inter_size=I_, num_layers=1, vocab=V, max_seq_len=seq + 1,
+                 rotary_dim=hs_, rotary_base=10000.0, rms_eps=1e-5)
+        xs = r.standard_normal((seq, H_)).astype(np.float32)
+        res = {}
+        for label, nt in (("all_threads", threads), ("one_thread", 1)):
+            orc.lib().orc_set_num_threads(nt)
+            tp, td = [], []
+            for _ in range(3 if nt > 1 else 1):
+                k_ = np.zeros((1, 1, nh_, seq + 1, hs_), np.float32)
+                v_ = np.zeros_like(k_)
+                a0 = time.perf_counter()
+                h = orc.context_decoder(c, [lw], xs, k_, v_, [seq], [0])
+                a1 = time.perf_counter()
+                orc.self_decoder(c, [lw], h[-1:], k_, v_, seq + 1)
+                a2 = time.perf_counter()
+                tp.append(a1 - a0)
+                td.append(a2 - a1)
+            res[label] = dict(cores=nt, prefill_tokens_per_s=round(seq / sorted(tp)[len(tp) // 2], 2),
+                              decode_tokens_per_s=round(1.0 / sorted(td)[len(td) // 2], 2))
+        orc.lib().orc_set_num_threads(threads)
+        res["sample"] = "%s: ONE layer, prefill of %d tokens then one decode step, fp32 oracle (all threads: median of 3 runs; one thread: one run)" % (note, seq)
+        return res
+
+    out["config_A"] = small("A", 4, 32, 344, 32, "config A (hidden 128, 4 heads, I 344, seq 32)")
+    out["config_B"] = small("B", nh, hs, I, 128, "config B (Llama-2-7B geometry, seq 128)")
+    return out
 
 
 def replica_aggregate(elapsed_s, tokens_this_rank, world):
@@ -237,6 +285,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the int8/int4/short-context side measurements")
+    ap.add_argument("--only", default="", help="profiling aid: run ONE configuration and print a short line: "
+                                               "decode:<f16|int8|int4|fp8>:<batch>:<ctx>[:kvfp8] or prefill:<f16|fp8>:<batch>:<seq>")
     ap.add_argument("--dry-run", action="store_true",
                     help="replica plumbing only (no GPU, no kernels): simulated per-rank times through the real launcher/aggregation")
     args = ap.parse_args()
@@ -379,6 +429,86 @@ def main():
         return t1 - t0, prof, solo
 
     P = 4
+
+    def run_prefill(b, s, wfmt="f16", layers=None, profile=False):
+        """prefill of b sequences x s tokens (packed), all layers; returns (seconds per pass, op profile or None, flops)"""
+        dec, kc, vc = make_decoder(torch, llmie, cfg, weights, layers or weights["layers"], wfmt, b, s)
+        T = b * s
+        ids = torch.randint(0, V, (T,), dtype=torch.int32, device=dev)
+        hid = torch.empty((T, H), dtype=torch.float16, device=dev)
+        lens = torch.full((b,), s, dtype=torch.int32, device=dev)
+        hist = torch.zeros(b, dtype=torch.int32, device=dev)
+
+        def once():
+            llmie.input_embedding(ids, weights["embed"], hid)
+            dec.prefill(hid, hid, kc, vc, lens, hist, s)
+
+        once()
+        torch.cuda.synchronize()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            once()
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / reps
+        pprof = None
+        if profile:
+            dec.profile_begin(2 * (cfg["num_layers"] * 12 + 8))
+            for _ in range(2):
+                once()
+            pprof = dec.profile_end()
+        Hh, KVH, I_, L_ = H, cfg["kv_head_num"] * cfg["head_size"], cfg["inter_size"], cfg["num_layers"]
+        flops = T * 2.0 * L_ * ((Hh + 2 * KVH) * Hh + Hh * Hh + 3 * Hh * I_) + b * L_ * 4.0 * Hh * s * (s + 1) / 2
+        dec.close()
+        del kc, vc, hid
+        torch.cuda.empty_cache()
+        return el, pprof, flops
+
+    def rocprof_ref(key):
+        """kernel averages of the committed rocprofv3 runs of these same configurations (profiles/r02_rocprof_roofline.json,
+        written by tools/summarize_prof.py from the kernel traces / PMC passes): the trace-side counterpart of the live
+        hipEvent numbers"""
+        try:
+            with open(os.path.join(ROOT, "profiles", "r02_rocprof_roofline.json")) as f:
+                return json.load(f).get(key)
+        except (OSError, ValueError):
+            return None
+
+    def roofline_block(kernel, bound, work_per_launch, us_per_launch, launches, peak, unit, ref_key):
+        """achieved = algorithmic work per launch / mean launch time.  Two time bases, named apart: frac_event = hipEvent
+        bracket around each launch on the launch stream, measured live in this run (includes the launch gap);
+        frac_rocprof_trace = the kernel's average duration in the committed rocprofv3 kernel trace of the same configuration.
+        `frac` is the live one."""
+        scale = 1e9 if unit == "GB/s" else 1e12
+        ach = work_per_launch / (us_per_launch * 1e-6) / scale
+        blk = dict(bound=bound, kernel=kernel, achieved=round(ach, 1), peak=peak, unit=unit, frac=round(ach / peak, 4),
+                   frac_event=round(ach / peak, 4), frac_rocprof_trace=None, traffic=None,
+                   algorithmic_work_per_launch=work_per_launch, us_per_launch=round(us_per_launch, 2), launches_timed=launches)
+        ref = rocprof_ref(ref_key)
+        if ref and not args.layers:
+            blk["rocprof_avg_us"] = ref.get("avg_us")
+            if ref.get("avg_us"):
+                blk["frac_rocprof_trace"] = round(work_per_launch / (ref["avg_us"] * 1e-6) / scale / peak, 4)
+            blk["traffic"] = ref.get("hbm_bytes_per_launch")
+            blk["rocprof_source"] = ref.get("source")
+        return blk
+
+    if args.only:
+        kind, fmt_, b_, s_ = args.only.split(":")[:4]
+        b_, s_ = int(b_), int(s_)
+        ql = weights["layers"] if fmt_ == "f16" else quantize_layers(torch, llmie, weights["layers"], fmt_)
+        if kind == "decode":
+            kv8 = args.only.endswith(":kvfp8")
+            el, pr, _ = run_decode(fmt_, ql, b_, s_, min(K, 32), min(W, 4), P, False, kv8)
+            print(json.dumps({"only": args.only, "tokens_per_s": round(b_ * min(K, 32) / el, 1), "ms_per_step": round(el / min(K, 32) * 1e3, 4),
+                              "ops_us_per_launch": {op: round(ms / n * 1e3, 2) for op, (ms, n) in pr.items() if n}}), flush=True)
+        else:
+            el, pr, fl = run_prefill(b_, s_, fmt_, ql, True)
+            print(json.dumps({"only": args.only, "tokens_per_s": round(b_ * s_ / el, 1), "ms": round(el * 1e3, 3),
+                              "TFLOP_per_s": round(fl / el / 1e12, 1),
+                              "ops_us_per_launch": {op: round(ms / n * 1e3, 2) for op, (ms, n) in pr.items() if n}}), flush=True)
+        return
+
     own_elapsed, prof, solo_elapsed = run_decode("f16", weights["layers"], B, S, K, W, P, True)
     value, elapsed = replica_aggregate(own_elapsed, B * K, world)
     per_replica = replica_gather(B * K / own_elapsed, world)
@@ -391,19 +521,8 @@ def main():
     gu_bytes = 2 * I * H * 2  # fused gate_up matrix streamed once per launch (180.4 MB)
     gu_ms, gu_n = prof["gate_up_swiglu"]
     gu_us = gu_ms / gu_n * 1e3
-    achieved = gu_bytes / (gu_us * 1e-6) / 1e9
-    roofline = dict(bound="hbm", kernel="gemv_ksplit_kernel<M=%d,RPW=8,XC=2,fp16> (RMSNorm + gate/up projection + SwiGLU)" % B,
-                    achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
-                    algorithmic_bytes_per_launch=gu_bytes, us_per_launch=round(gu_us, 2), launches_timed=gu_n)
-    try:  # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (profiles/), if present
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            pm = json.load(f)
-        if B == 1 and not args.layers:
-            roofline["traffic"] = round(pm["hbm_bytes_per_launch"])
-            roofline["traffic_source"] = pm["source"]
-    except (OSError, ValueError, KeyError):
-        pass
+    roofline = roofline_block("gemv_ksplit_kernel<M=%d,RPW=8,XC=2,fp16> (RMSNorm + gate/up projection + SwiGLU)" % B, "hbm", gu_bytes,
+                              gu_us, gu_n, HBM_PEAK_GBS, "GB/s", "decode_f16_b1_ctx2048" if (B == 1 and S == 2048) else "")
     step_bytes = decode_bytes_per_step(cfg, B, S)
     whole = dict(algorithmic_bytes_per_step=step_bytes,
                  achieved_GBs=round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
@@ -429,44 +548,22 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra:
         extra = {}
 
-        def record(name, wfmt, layers, b, s, wbytes, kv_fp8=False):
+        def record(name, wfmt, layers, b, s, wbytes, kv_fp8=False, profile=False):
             k, w_ = min(K, 32), min(W, 4)
-            el, _, _ = run_decode(wfmt, layers, b, s, k, w_, 0, False, kv_fp8)
+            el, pr, _ = run_decode(wfmt, layers, b, s, k, w_, P if profile else 0, False, kv_fp8)
             ms = el / k * 1e3
             nbytes = decode_bytes_per_step(cfg, b, s, wbytes, 1 if kv_fp8 else 2)
             extra[name] = dict(tokens_per_s=round(b * k / el, 1), ms_per_step=round(ms, 4), batch=b, ctx=s,
                                algorithmic_GB_per_step=round(nbytes / 1e9, 3),
                                frac_of_hbm_peak=round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+            return pr
 
-        def record_prefill(name, b, s, wfmt="f16", layers=None):
-            """prefill of b sequences x s tokens (packed), all 32 layers"""
-            dec, kc, vc = make_decoder(torch, llmie, cfg, weights, layers or weights["layers"], wfmt, b, s)
-            T = b * s
-            ids = torch.randint(0, V, (T,), dtype=torch.int32, device=dev)
-            hid = torch.empty((T, H), dtype=torch.float16, device=dev)
-            lens = torch.full((b,), s, dtype=torch.int32, device=dev)
-            hist = torch.zeros(b, dtype=torch.int32, device=dev)
-
-            def once():
-                llmie.input_embedding(ids, weights["embed"], hid)
-                dec.prefill(hid, hid, kc, vc, lens, hist, s)
-
-            once()
-            torch.cuda.synchronize()
-            reps = 3
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                once()
-            torch.cuda.synchronize()
-            el = (time.perf_counter() - t0) / reps
-            Hh, KVH, I_, L_ = H, cfg["kv_head_num"] * cfg["head_size"], cfg["inter_size"], cfg["num_layers"]
-            flops = T * 2.0 * L_ * ((Hh + 2 * KVH) * Hh + Hh * Hh + 3 * Hh * I_) + b * L_ * 4.0 * Hh * s * (s + 1) / 2
-            extra[name] = dict(tokens_per_s=round(T / el, 1), ms=round(el * 1e3, 3), batch=b, seq=s,
+        def record_prefill(name, b, s, wfmt="f16", layers=None, profile=False):
+            el, pr, flops = run_prefill(b, s, wfmt, layers, profile)
+            extra[name] = dict(tokens_per_s=round(b * s / el, 1), ms=round(el * 1e3, 3), batch=b, seq=s,
                                TFLOP_per_s=round(flops / el / 1e12, 1),
                                frac_of_mfma_peak=round(flops / el / (5.0e15 if wfmt == "fp8" else 2.5e15), 4))
-            dec.close()
-            del kc, vc, hid
-            torch.cuda.empty_cache()
+            return pr
 
         if os.environ.get("LLMIE_BENCH_SMALL_BATCH_SWEEP"):  # development: small-batch decode over the weight formats
             for fmt_, wb_ in (("f16", 2.0), ("int8", 1.0), ("fp8", 1.0), ("int4", 0.5 + 2.0 / 128)):
@@ -477,12 +574,27 @@ def main():
                 torch.cuda.empty_cache()
             print(json.dumps({k: v["tokens_per_s"] for k, v in extra.items()}), flush=True)
             return
-        record_prefill("prefill_f16_b1_s2048", 1, 2048)
+        pp = record_prefill("prefill_f16_b1_s2048", 1, 2048, profile=True)
+        if pp and pp.get("gate_up_swiglu", (0, 0))[1]:
+            # dominant prefill kernel: the gate/up projection GEMM with the SwiGLU epilogue (2 * T * 2I * H flops per launch)
+            ms_, n_ = pp["gate_up_swiglu"]
+            out["roofline_prefill"] = roofline_block(
+                "gemm256 LDS-DMA MFMA kernel, 256 x 256 tiles (gate/up projection + SwiGLU epilogue), T = 2048", "mfma",
+                2.0 * 2048 * 2 * cfg["inter_size"] * H, ms_ / n_ * 1e3, n_, 2500.0, "TFLOP/s", "prefill_f16_b1_s2048")
+            out["roofline_prefill"]["whole_pass"] = dict(extra["prefill_f16_b1_s2048"])
         record_prefill("prefill_f16_b8_s512", 8, 512)
         record_prefill("prefill_f16_b1_s128", 1, 128)   # BASELINE configs[1] shape (all 32 layers)
         q8 = quantize_layers(torch, llmie, weights["layers"], "int8")
         record("decode_int8_b1_ctx2048", "int8", q8, 1, 2048, 1.0)
-        record("decode_int8_b32_ctx128", "int8", q8, 32, 128, 1.0)   # BASELINE configs[3]
+        p8 = record("decode_int8_b32_ctx128", "int8", q8, 32, 128, 1.0, profile=True)   # BASELINE configs[3]
+        if p8 and p8.get("gate_up_swiglu", (0, 0))[1]:
+            # dominant kernel of the int8 batch step: the packed-weight gate/up projection (RMSNorm prologue, SwiGLU epilogue)
+            ms_, n_ = p8["gate_up_swiglu"]
+            out["roofline_int8"] = roofline_block(
+                "pk_mfma_kernel<MT=2,int8,SwiGLU,x32> (RMSNorm + gate/up projection + SwiGLU on the tile-packed int8 image), batch 32",
+                "hbm", 2 * cfg["inter_size"] * H * 1, ms_ / n_ * 1e3, n_, HBM_PEAK_GBS, "GB/s", "decode_int8_b32_ctx128")
+            out["roofline_int8"]["whole_step"] = dict(extra["decode_int8_b32_ctx128"])
+            out["roofline_int8"]["ops_us_per_launch"] = {op: round(ms / n * 1e3, 2) for op, (ms, n) in p8.items() if n}
         record("decode_int8_b32_ctx2048", "int8", q8, 32, 2048, 1.0)          # KV-dominated (SURVEY 8d cfg D)
         record("decode_int8_b32_ctx2048_kvfp8", "int8", q8, 32, 2048, 1.0, True)   # same with the e4m3 KV cache
         record("decode_f16_b1_ctx128", "f16", weights["layers"], 1, 128, 2.0)

@@ -164,18 +164,20 @@ static size_t engine_slab_floats(const llmie_decoder_config *c, int rows) {
     }
     if (c->dtype != LLMIE_F16) return 0;
     const int H = c->head_num * c->head_size, QKV = (c->head_num + 2 * c->kv_head_num) * c->head_size, I = c->inter_size;
-    const int shapes[4][2] = {{H, QKV}, {H, H}, {H, 2 * I}, {I, H}};
+    const int shapes[5][2] = {{H, QKV}, {H, H}, {H, 2 * I}, {I, H}, {H, c->vocab_size}};   // (the LM head of llmie_lm_head_sample)
     size_t m = 0;
-    for (int r = 1; r <= rows; r = r < 16 ? r + 1 : r + 16) {   // the plan changes with the row count (forms, slices)
-        const int rr = r > rows ? rows : r;
-        for (const auto &sh : shapes) {
-            const size_t f = linear_splitk_ws_floats(wbits, rr, sh[0], sh[1]);
+    // every row count up to `rows` (the plan -- kernel form, K slices -- changes with it); the LM head may come in a different
+    // format than the layers (fp16 beside int8 / fp8 layers): all formats for that shape
+    const int lm_bits[4] = {16, 8, 4, WF_FP8};
+    for (int r = 1; r <= rows; ++r) {
+        for (int i = 0; i < 4; ++i) {
+            const size_t f = linear_splitk_ws_floats(wbits, r, shapes[i][0], shapes[i][1]);
             m = f > m ? f : m;
         }
-    }
-    for (const auto &sh : shapes) {
-        const size_t f = linear_splitk_ws_floats(wbits, rows, sh[0], sh[1]);
-        m = f > m ? f : m;
+        for (int b : lm_bits) {
+            const size_t f = linear_splitk_ws_floats(b, r, shapes[4][0], shapes[4][1]);
+            m = f > m ? f : m;
+        }
     }
     return m;
 }

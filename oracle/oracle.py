@@ -312,3 +312,34 @@ def self_decoder(cfg, layers, hidden, k_cache, v_cache, step):
     lib().orc_self_decoder(C.byref(c), arr, _p(hidden), _p(k_cache), _p(v_cache), C.c_int(bs), C.c_int(step),
                            _p(scratch))
     return hidden
+
+
+def context_decoder(cfg, layers, x, k_cache, v_cache, lens, hist):
+    """LlamaContextDecoder::forward restated over the kernel oracles (context_decoder.cpp:58-199, context_attention.cpp:143-312,
+    ffn.cpp:76-144): packed tokens x [T, H] of `lens` new tokens per sequence behind `hist` cached ones; caches updated in place."""
+    nh, kvh, hs, I = cfg["head_num"], cfg["kv_head_num"], cfg["head_size"], cfg["inter_size"]
+    eps = cfg.get("rms_eps", 1e-5)
+    bs, T = len(lens), int(sum(lens))
+    mq = int(max(lens))
+    ctx = np.array([l + h for l, h in zip(lens, hist)], np.int32)
+    mk = int(ctx.max())
+    H = nh * hs
+    off, _ = cal_padding_offset(lens, mq, fill=0)
+    off = off.reshape(-1)[:T]
+    mask = build_causal_mask(lens, ctx, mq, mk)
+    h = x.copy()
+    for l, w in enumerate(layers):
+        hn, resid = rmsnorm(h, w["attn_norm"], eps)
+        qkv = linear(hn, w["qkv"]).reshape(T, nh + 2 * kvh, hs)
+        q, k, v = qkv_bias_transpose_rope(qkv, w.get("qkv_bias"), off, hist, bs, mq, nh, kvh, hs, cfg.get("rotary_dim", hs),
+                                          cfg.get("rotary_base", 10000.0), fill=0.0)
+        concat_kv(k, k_cache, lens, hist, l)
+        concat_kv(v, v_cache, lens, hist, l)
+        kr, vr = repeat_kv(k_cache, ctx, l, nh, mk), repeat_kv(v_cache, ctx, l, nh, mk)
+        p = scale_mask_softmax(batched_gemm(q, kr, True), mask, 1.0 / np.sqrt(hs))
+        att = transpose_remove_padding(batched_gemm(p, vr, False), off, T).reshape(T, H)
+        o = linear(att, w["o"])
+        hn2, resid2 = fused_add_bias_residual_rmsnorm(resid, o, w.get("o_bias"), w["ffn_norm"], eps)
+        act = silu_and_mul(linear(hn2, w["gate_up"]).reshape(T, 2, I))
+        h = add_residual(resid2, linear(act, w["down"]))
+    return h

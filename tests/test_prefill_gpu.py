@@ -35,30 +35,9 @@ def _engine(llmie, layers, nh, kvh, hs, I, max_seq, max_batch):
 
 
 def oracle_prefill(layers, x, kc, vc, lens, hist, nh, kvh, hs, I, max_seq):
-    """kc/vc updated in place; returns hidden [T,H]"""
-    bs, T = len(lens), int(sum(lens))
-    mq = int(max(lens))
-    ctx = np.array([l + h for l, h in zip(lens, hist)], np.int32)
-    mk = int(ctx.max())
-    H = nh * hs
-    off, _ = orc.cal_padding_offset(lens, mq, fill=0)
-    off = off.reshape(-1)[:T]
-    mask = orc.build_causal_mask(lens, ctx, mq, mk)
-    h = x.copy()
-    for l, w in enumerate(layers):
-        hn, resid = orc.rmsnorm(h, w["attn_norm"], 1e-5)
-        qkv = orc.linear(hn, w["qkv"]).reshape(T, nh + 2 * kvh, hs)
-        q, k, v = orc.qkv_bias_transpose_rope(qkv, None, off, hist, bs, mq, nh, kvh, hs, hs, 10000.0, fill=0.0)
-        orc.concat_kv(k, kc, lens, hist, l)
-        orc.concat_kv(v, vc, lens, hist, l)
-        kr, vr = orc.repeat_kv(kc, ctx, l, nh, mk), orc.repeat_kv(vc, ctx, l, nh, mk)
-        p = orc.scale_mask_softmax(orc.batched_gemm(q, kr, True), mask, 1.0 / np.sqrt(hs))
-        att = orc.transpose_remove_padding(orc.batched_gemm(p, vr, False), off, T).reshape(T, H)
-        o = orc.linear(att, w["o"])
-        hn2, resid2 = orc.fused_add_bias_residual_rmsnorm(resid, o, w["o_bias"], w["ffn_norm"], 1e-5)
-        act = orc.silu_and_mul(orc.linear(hn2, w["gate_up"]).reshape(T, 2, I))
-        h = orc.add_residual(resid2, orc.linear(act, w["down"]))
-    return h
+    """kc/vc updated in place; returns hidden [T,H] (the oracle front-end's composition of the kernel oracles)"""
+    cfg = dict(head_num=nh, kv_head_num=kvh, head_size=hs, inter_size=I, rms_eps=1e-5, rotary_dim=hs, rotary_base=10000.0)
+    return orc.context_decoder(cfg, layers, x, kc, vc, lens, hist)
 
 
 CASES = [("single_40", 8, 8, 1376, 2, [40], [0]), ("ragged_hist", 8, 8, 1376, 2, [70, 5, 33], [0, 10, 64]),

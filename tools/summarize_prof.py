@@ -6,6 +6,11 @@
   python tools/summarize_prof.py pmc    <fetch_dir> <write_dir> <out.csv> <out.json> <kernel substring> <grid>
       HBM bytes per launch from two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; KiB units; FETCH_SIZE x2 on gfx950
       for wide coalesced streaming reads, MI355X_MICROARCH.md HBM section)
+  python tools/summarize_prof.py sq     <pmc_dir> <out.csv> "<command line>" [kernel substring ...]
+      per-kernel averages of every SQ counter of one --pmc pass, plus the derived ratios (MFMA busy, waits, LDS conflicts)
+  python tools/summarize_prof.py roofline <out.json> <key> <trace_dir> <kernel substring> <grid or 0> <stats csv> [<pmc json>]
+      adds/replaces entry <key> of the JSON bench.py reads for its *_rocprof_trace fractions: the kernel's average duration
+      in the kernel trace (and its PMC HBM bytes per launch)
 """
 import csv, glob, json, os, sys
 from collections import defaultdict
@@ -78,8 +83,71 @@ def pmc(dfetch, dwrite, out, out_json, kernel_sub, grid):
     print("wrote", out, "and" if pick else "(kernel not found for)", out_json)
 
 
+def sq(d, out, cmd, subs):
+    acc, grids = defaultdict(lambda: defaultdict(list)), {}
+    with open(find(d, "counter_collection.csv")) as f:
+        for r in csv.DictReader(f):
+            n = r["Kernel_Name"]
+            if "llmie" not in n or (subs and not any(x in n for x in subs)):
+                continue
+            key = (n, int(r["Grid_Size"]))
+            acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    names = sorted({c for v in acc.values() for c in v})
+    with open(out, "w") as f:
+        f.write("# %s\n# per (kernel, grid): mean counter value per launch; SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles\n"
+                "# summed over waves, SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs (MI355X_MICROARCH.md, counter table)\n" % cmd)
+        f.write("# mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES * 32): SQ_BUSY_CYCLES is summed over the 32 shader engines\n"
+                "#   (8 XCDs x 4), so SQ_BUSY_CYCLES / 32 = kernel duration in shader cycles and x 1024 SIMDs = all SIMD cycles;\n"
+                "#   wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES;\n"
+                "#   issue_stall_frac = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES; lds_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE\n")
+        f.write("Name,Grid,Launches," + ",".join(names) + ",mfma_busy_frac,wait_frac,issue_stall_frac,lds_conflict_frac\n")
+        for key in sorted(acc, key=lambda k: -sum(acc[k].get("SQ_WAVE_CYCLES", [0]))):
+            v = {c: sum(x) / len(x) for c, x in acc[key].items()}
+            n_l = max(len(x) for x in acc[key].values())
+
+            def ratio(a, b, k=1.0):
+                return "%.4f" % (v[a] / (v[b] * k)) if a in v and b in v and v[b] > 0 else ""
+            f.write('"%s",%d,%d,%s,%s,%s,%s,%s\n' % (short(key[0]), key[1], n_l, ",".join("%.0f" % v.get(c, 0.0) for c in names),
+                                                   ratio("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", 32.0), ratio("SQ_WAIT_ANY", "SQ_WAVE_CYCLES"),
+                                                   ratio("SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES"), ratio("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE")))
+    print("wrote", out)
+
+
+def roofline(out_json, key, d, kernel_sub, grid, stats_csv, pmc_json=None):
+    durs = []
+    with open(find(d, "kernel_trace.csv")) as f:
+        for r in csv.DictReader(f):
+            if kernel_sub in r["Kernel_Name"]:
+                g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+                if int(grid) in (0, g):
+                    durs.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                    name = r["Kernel_Name"]
+    if not durs:
+        raise SystemExit("kernel %s (grid %s) not in %s" % (kernel_sub, grid, d))
+    try:
+        with open(out_json) as f:
+            data = json.load(f)
+    except (OSError, ValueError):
+        data = {}
+    e = dict(kernel=short(name), grid=int(grid), calls=len(durs), avg_us=round(sum(durs) / len(durs) / 1e3, 3),
+             source="%s (rocprofv3 --kernel-trace, eager launches)" % stats_csv)
+    if pmc_json:
+        with open(pmc_json) as f:
+            pj = json.load(f)
+        e["hbm_bytes_per_launch"] = round(pj["hbm_bytes_per_launch"])
+        e["traffic_source"] = pj["source"]
+    data[key] = e
+    with open(out_json, "w") as f:
+        json.dump(data, f, indent=1, sort_keys=True)
+    print("wrote", out_json, key, e["avg_us"], "us x", len(durs))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif sys.argv[1] == "sq":
+        sq(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5:])
+    elif sys.argv[1] == "roofline":
+        roofline(*sys.argv[2:9])
     else:
         pmc(*sys.argv[2:8])
