@@ -119,14 +119,8 @@ __device__ __forceinline__ size_t attn_out_index(int x32, int b, int k, int widt
 // Merge of the per-split (m, l, o[d]) partials of one (batch, head) for output dim d: 16 splits per round,
 // every load of a round issued before the first use.  Shared by the stand-alone merge kernel and by the
 // in-kernel merge of the last-arriving workgroup, so both give bit-identical results.
-// COHERENT: agent-scope relaxed atomic loads (served at the memory side, past the per-XCD L2) for partials that other
-// XCDs wrote with agent-scope stores and no release fence (experimental in-launch merge, LLMIE_ATTN_MERGE_IN_KERNEL=2)
-template <bool COHERENT = false>
 __device__ __forceinline__ float merge_splits(const float *__restrict__ p, int nsplits, size_t stride, int d) {
-    auto ld = [&](const float *q) -> float {
-        if constexpr (COHERENT) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else return *q;
-    };
+    auto ld = [&](const float *q) -> float { return *q; };
     float M = -INFINITY, L = 0.f, o = 0.f;
     for (int s0 = 0; s0 < nsplits; s0 += 16) {
         float ms[16], ls[16], os[16];
@@ -163,7 +157,6 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
     int step_arg, const int32_t *__restrict__ step_dev, int max_splits,
     const float2 *__restrict__ rope /* [max_pos][HS/2] (cos,sin) or null */, int rotary_dim,
     int32_t *tickets /* [batch, kv_head_num] zero-initialised arrival counters, or null = separate merge kernel */,
-    const int wt_merge /* in-launch merge only: 1 = experimental write-through hand-off (no release / acquire fences) */,
     const QkvSlabs qs /* qs.slab != null: q/k/v come from the split-K partial slabs of the QKV projection (qkv unused) */,
     const float k_scale, const float v_scale /* fp8 cache: stored = e4m3(x / scale); 1 otherwise */,
     const PagedKv pg /* pg.table != null: k_cache / v_cache are this layer's page pools */) {
@@ -485,18 +478,10 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
             out[attn_out_index(pg.out_x32, b, h * HS + d, head_num * HS)] = from_f32<T>(o / (L + 1e-6f));
         } else {
             float *p = part + ((static_cast<size_t>(b) * head_num + h) * max_splits + split) * (HS + 2);
-            if (wt_merge) {  // write-through (agent-scope) stores: visible at the memory side once vmcnt drains
-                __hip_atomic_store(p + 2 + d, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (d == 0) {
-                    __hip_atomic_store(p, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(p + 1, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            } else {
-                p[2 + d] = o;
-                if (d == 0) {
-                    p[0] = M;
-                    p[1] = L;
-                }
+            p[2 + d] = o;
+            if (d == 0) {
+                p[0] = M;
+                p[1] = L;
             }
         }
     }
@@ -511,19 +496,15 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
         __syncthreads();
         int32_t *cnt = tickets + static_cast<size_t>(b) * kv_head_num + g;
         if (threadIdx.x == 0) {
-            if (!wt_merge) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             s_ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         if (s_ticket == nsplits - 1) {  // workgroup-uniform
             if (threadIdx.x == 0) {
-                if (!wt_merge) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
             }
             __syncthreads();
@@ -532,7 +513,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
                 const int r = i / HS, d = i - r * HS;
                 const int h = g * REP + r;
                 const float *p = part + (static_cast<size_t>(b) * head_num + h) * max_splits * stride;
-                const float v = wt_merge ? merge_splits<true>(p, nsplits, stride, d) : merge_splits<false>(p, nsplits, stride, d);
+                const float v = merge_splits(p, nsplits, stride, d);
                 out[attn_out_index(pg.out_x32, b, h * HS + d, head_num * HS)] = from_f32<T>(v);
             }
         }
@@ -555,7 +536,7 @@ __global__ __launch_bounds__(256) void decode_attn_combine_kernel(const float *_
     const size_t stride = static_cast<size_t>(head_size) + 2;
     const float *p = part + (static_cast<size_t>(b) * head_num + h) * max_splits * stride;
     for (int d = threadIdx.x; d < head_size; d += blockDim.x)
-        out[attn_out_index(out_x32, b, h * head_size + d, head_num * head_size)] = from_f32<T>(merge_splits<false>(p, nsplits, stride, d));
+        out[attn_out_index(out_x32, b, h * head_size + d, head_num * head_size)] = from_f32<T>(merge_splits(p, nsplits, stride, d));
 }
 
 // Any head size / GQA ratio (e.g. the reference unit test's hs=4): one workgroup per (b, q-head),
@@ -626,8 +607,6 @@ static void launch_split(const T *qkv, const T *bias, KT *kc, KT *vc, float *par
                          int head_num, int kv_head_num, int max_seq_len, int step, const int32_t *step_dev,
                          int max_splits_ws, const float2 *rope, int rot_dim, int32_t *tickets, const QkvSlabs &qs,
                          KvScale ks, PagedKv pg, hipStream_t st) {
-    static const int cfg = getenv("LLMIE_ATTN_CFG") ? atoi(getenv("LLMIE_ATTN_CFG")) : 0;
-    static const bool wt = getenv("LLMIE_ATTN_MERGE_IN_KERNEL") && atoi(getenv("LLMIE_ATTN_MERGE_IN_KERNEL")) == 2;
     const int bound = step_dev ? max_seq_len : step;
     int CHUNK, splits;
 #define LLMIE_ATTN_LAUNCH(NWV_, GL_)                                                                                   \
@@ -637,11 +616,9 @@ static void launch_split(const T *qkv, const T *bias, KT *kc, KT *vc, float *par
         dim3 grid(splits, kv_head_num, batch);                                                                          \
         decode_attn_split_kernel<T, HS, REP, NWV_, GL_, KT><<<grid, NWV_ * 64, 0, st>>>(                                \
             qkv, bias, kc, vc, part, out, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, \
-            tickets, wt ? 1 : 0, qs, ks.k, ks.v, pg);                                                                   \
+            tickets, qs, ks.k, ks.v, pg);                                                                               \
     } while (0)
-    if (cfg == 1) LLMIE_ATTN_LAUNCH(8, 8);
-    else if (cfg == 2) LLMIE_ATTN_LAUNCH(4, 4);
-    else LLMIE_ATTN_LAUNCH(4, 8);
+    LLMIE_ATTN_LAUNCH(4, 8);   // 4 waves, 8 K + 8 V loads in flight per lane (8 waves x 8 and 4 x 4 measured slower, round 1)
 #undef LLMIE_ATTN_LAUNCH
     if (splits > 1 && !tickets) {
         dim3 cgrid(head_num, batch);

@@ -33,7 +33,6 @@ struct llmie_decoder {
     size_t fp8_ws_bytes;
     SlabWs slab_ws;      // fp32 slabs of the split-K projections (batch path, row-major engines)
     int ragged = 0;      // set for the duration of a *_ragged forward: step_dev is the per-sequence context-length array
-    int32_t *tickets;    // [max_batch, kv_head_num] arrival counters of the in-launch attention merge (zero between launches)
     // packed-weight batch path (gemv_max < batch <= 32): tile-packed images of the four matrices of every layer (built once at
     // create time into the caller's workspace: the MI355X's 288 GB buy a second, stream-friendly copy of the weights), the
     // activations between the packed kernels in the x32 layout, and the split-K slabs of the down projection
@@ -196,7 +195,7 @@ static size_t carve(const llmie_decoder_config *c, size_t *offs /*[12]*/) {
     offs[5] = k.take(B * 2 * I * e);    // gate_up (unfused paths)
     offs[6] = k.take(llmie_decoder_mha_workspace_bytes(c->max_batch, c->head_num, c->head_size, c->max_seq_len));
     offs[7] = k.take(static_cast<size_t>(c->max_seq_len) * (c->head_size / 2) * sizeof(float2));  // RoPE table
-    offs[8] = k.take(static_cast<size_t>(c->max_batch) * c->kv_head_num * sizeof(int32_t));         // merge tickets
+    offs[8] = k.take(256);   // (spare)
     const int kmax = c->inter_size > static_cast<int>(H) ? c->inter_size : static_cast<int>(H);
     // fp8: three activation-quantisation units (normed input, attention output, SwiGLU output), see decoder_forward
     offs[9] = k.take(c->wfmt == LLMIE_W_FP8 ? 3 * llmie_linear_fp8_workspace_bytes(c->max_batch, kmax, 0) : 256);
@@ -261,7 +260,6 @@ extern "C" llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg, 
     d->attn_ws = base + offs[6];
     d->attn_ws_bytes = llmie_decoder_mha_workspace_bytes(cfg->max_batch, cfg->head_num, cfg->head_size, cfg->max_seq_len);
     d->rope_table = reinterpret_cast<float2 *>(base + offs[7]);
-    d->tickets = reinterpret_cast<int32_t *>(base + offs[8]);
     d->fp8_ws = base + offs[9];
     {
         const int kmax = cfg->inter_size > d->H ? cfg->inter_size : d->H;
@@ -299,11 +297,6 @@ extern "C" llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg, 
             delete d;
             return nullptr;
         }
-    }
-    if (hipMemset(d->tickets, 0, static_cast<size_t>(cfg->max_batch) * cfg->kv_head_num * sizeof(int32_t)) != hipSuccess) {
-        set_error("decoder_create: ticket memset failed");
-        delete d;
-        return nullptr;
     }
     {
         // cos/sin of angle = pos / base^(2j/rot_dim) (rope_utils.cuh:6-19), evaluated on the host in fp32 with libm --
@@ -450,11 +443,10 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
     const bool fp8 = c.wfmt == LLMIE_W_FP8;
     const int kv8 = c.kv_fmt == LLMIE_KV_FP8;
     const float k_scale = c.k_scale > 0.f ? c.k_scale : 1.f, v_scale = c.v_scale > 0.f ? c.v_scale : 1.f;
-    // GEMV form up to LLMIE_GEMV_MAX_BATCH rows (its dot products are VALU work that grows with the batch), MFMA split-K above
-    static const int gemv_max_env = getenv("LLMIE_GEMV_MAX_BATCH") ? atoi(getenv("LLMIE_GEMV_MAX_BATCH")) : -1;
+    // GEMV form up to gemv_max rows (its dot products are VALU work that grows with the batch), MFMA split-K above
     // measured crossover on MI355X (7B, ctx 512, tokens/s GEMV vs split-K): fp16 b4 1157/1143, b6 1496/1592; int8 b4 1416/1404,
     // b6 1672/1962; fp8 b3 947/944, b4 1127/1213; int4 b2 796/745, b3 896/1074
-    const int gemv_max = gemv_max_env >= 0 ? gemv_max_env : (fp8 ? 3 : (wbits == 4 ? 2 : 4));
+    const int gemv_max = fp8 ? 3 : (wbits == 4 ? 2 : 4);
     static const int batch_fused_off = getenv("LLMIE_NO_FUSED_BATCH") ? 1 : 0;
     const bool int4_ok = wbits == 4 && c.int4_group == 128 && batch <= 64;  // int4 MFMA form: group-128 scales, 64 rows per pass
     const bool batch_path_ok = !batch_fused_off && c.dtype == LLMIE_F16 && (wbits == 16 || wbits == 8 || int4_ok || fp8) && hs_ok &&
@@ -464,10 +456,9 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
                                       : ((wbits != 0 || fp8) && ksplit_eligible(batch, H, fp8 ? 8 : wbits)));
     if (!fused_off && c.dtype == LLMIE_F16 && (wbits != 0 || fp8) && hs_ok && rep_ok && H % 8 == 0 && gemv_ok) {
         hipStream_t st = as_stream(stream);
-        // In-launch merge of the attention partials (ticket + agent-scope release/acquire) measured SLOWER than the
-        // separate 4.8 us merge kernel on MI355X (2.97 vs 2.81 ms per token: every workgroup pays the release fence),
-        // so the merge kernel is the default; LLMIE_ATTN_MERGE_IN_KERNEL=1 selects the single-launch form.
-        static const bool merge_in_kernel = getenv("LLMIE_ATTN_MERGE_IN_KERNEL") != nullptr;
+        // (the in-launch merge of the attention partials -- the tickets argument of llmie_decoder_mha_rope -- measured SLOWER than the
+        // separate 4.8 us merge kernel on MI355X, 2.97 vs 2.81 ms per token: every workgroup pays the release fence; the engine
+        // always uses the merge kernel)
         // y = [swiglu]( rmsnorm(x + pre_bias)*gamma . W^T ) + residual on the streaming GEMV of the weight format
         auto lin = [&](const void *x, const llmie_matrix &w, void *y, int K, int N, int epi, const void *residual,
                        const void *gamma, const void *pre_bias) -> int {
@@ -503,7 +494,7 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
             TIMED(LLMIE_OP_MHA, decoder_mha_rope(dec->qkv, w.qkv.bias, k_cache, v_cache, dec->mha, l, batch, c.head_num,
                                                  c.kv_head_num, c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws,
                                                  dec->attn_ws_bytes, dec->rope_table, c.rotary_dim,
-                                                 (merge_in_kernel && !kv8 && !dec->page_table) ? dec->tickets : nullptr, dt, st, nullptr,
+                                                 nullptr, dt, st, nullptr,
                                                  nullptr, kv8, k_scale, v_scale, dec->page_table, dec->max_pages, dec->num_pages,
                                                  dec->ragged));
             TIMED(LLMIE_OP_O_GEMM, lin(dec->mha, w.o, h, H, H, EPI_NONE_, h, nullptr, nullptr));

@@ -8,17 +8,6 @@
 
 namespace llmie {
 
-static int env_int(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
-// LLMIE_DECODE_GEMM: 0 = auto, 1 = force fdot2 GEMV (M<=8), 2 = force skinny MFMA
-static int decode_gemm_mode() {
-    static int mode = env_int("LLMIE_DECODE_GEMM", 0);
-    return mode;
-}
-
 // ---- decode GEMV dispatch ----
 // K-split kernel: XC = 16-byte chunks per thread = ceil(K*WBITS/128/256) rounded up to {1,2,3,4,6,8}; RPW rows per
 // iteration so that RPW*XC ~ 16 loads are in flight per lane; register budget M*XC*XE <= 16 half8 of activations.
@@ -26,7 +15,7 @@ template <int M, int RPW, int XC, int WBITS, bool DB = false, bool FP8 = false> 
     const bool swiglu = a.epi == EPI_SWIGLU;
     const int groups = swiglu ? (a.N / 2 + RPW / 2 - 1) / (RPW / 2) : (a.N + RPW - 1) / RPW;
     // long-lived workgroups (the prologue -- activation slice + norm -- is paid once per workgroup), evenly loaded
-    static const int target = env_int("LLMIE_GEMV_TARGET_WGS", 768);
+    constexpr int target = 768;
     const int iters = (groups + target - 1) / target;
     const int grid = (groups + iters - 1) / iters;
     gemv_ksplit_kernel<M, RPW, XC, WBITS, DB, FP8><<<grid, 256, 0, st>>>(a);
@@ -488,9 +477,7 @@ int splitk_rownorm(const SplitKSlabs &sk, const SlabScale &wscale, const half_t 
 
 // does the GEMV family take (M, K)?  (K-split register budget, else the LDS fallback's 64 KB)
 bool gemv_f16_eligible(int M, int K, const void *x, const void *W) {
-    if (K % 8 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) % 16) || M < 1 || M > 8 ||
-        decode_gemm_mode() == 2)
-        return false;
+    if (K % 8 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) % 16) || M < 1 || M > 8) return false;
     return ksplit_eligible(M, K, 16) || static_cast<size_t>(M) * K * 2 <= 64 * 1024;
 }
 
@@ -509,11 +496,11 @@ int linear_f16_nk_norm(const half_t *x, const half_t *W, half_t *y, int M, int K
 // 256 x 256 (or 256 x 128) LDS-DMA GEMM (gemm256.cuh): fp16 operands, or e4m3 operands with per-token / per-row scales.
 // Tile choice by grid fill: 256-wide column tiles when they give >= min_tiles workgroups (one per CU), else 128-wide.
 static int g256_group_m() {
-    static const int v = env_int("LLMIE_GEMM256_GROUP_M", 4);
+    constexpr int v = 4;
     return v;
 }
 static int gemm256_wn(int M, int N) {
-    static const int min_tiles = env_int("LLMIE_GEMM256_MIN_TILES", 192);
+    constexpr int min_tiles = 192;
     const int tm = (M + 255) / 256;
     if (tm * ((N + 255) / 256) >= min_tiles) return 4;
     if (tm * ((N + 127) / 128) >= min_tiles) return 2;
@@ -537,8 +524,8 @@ static void gemm256_launch_t(const void *x, const void *W, half_t *y, int M, int
 
 // SwiGLU form: W = fused gate_up [2I, K], y = silu(x.Wg^T) * (x.Wu^T) [M, I]
 bool gemm256_swiglu_fills(int M, int two_inter) {
-    static const int min_tiles = env_int("LLMIE_GEMM256_MIN_TILES", 192);
-    static const bool off = getenv("LLMIE_GEMM256_NO_SWIGLU") != nullptr;
+    constexpr int min_tiles = 192;
+    constexpr bool off = false;
     return !off && two_inter % 8 == 0 && ((M + 255) / 256) * ((two_inter / 2 + 127) / 128) >= min_tiles;
 }
 void gemm256_swiglu_launch(bool fp8, const void *x, const void *W, half_t *y, int M, int two_inter, int K, const float *xscale,
@@ -585,8 +572,8 @@ static void gemm256_range(bool fp8, int wn, const void *x, const void *W, half_t
 // tiles = 1.5 rounds) is avoided by running the full rounds 256-wide and the remaining columns 128-wide in a second launch.
 void gemm256_launch(bool fp8, const void *x, const void *W, half_t *y, int M, int N, int K, const half_t *bias,
                     const half_t *residual, const float *xscale, const float *wscale, hipStream_t st) {
-    static const int cus = env_int("LLMIE_GEMM256_CUS", 256);
-    static const bool no_split = getenv("LLMIE_GEMM256_NO_SPLIT") != nullptr;
+    constexpr int cus = 256;
+    constexpr bool no_split = false;
     const int tm = (M + 255) / 256, tn4 = (N + 255) / 256, tn2 = (N + 127) / 128;
     const int tiles4 = tm * tn4, tiles2 = tm * tn2;
     auto rounds = [&](int t) { return (t + cus - 1) / cus; };

@@ -343,8 +343,8 @@ int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, void *k_cache, vo
     }
     const size_t layer_off = block_table ? static_cast<size_t>(layer) * num_pages * kv_head_num * 128 * head_size
                                          : static_cast<size_t>(layer) * batch * kv_head_num * max_seq_len * head_size;
-    static const int nw = getenv("LLMIE_PF_NW") ? atoi(getenv("LLMIE_PF_NW")) : 8;  // waves per workgroup (x 16 query rows)
-    const int bq = (nw == 4 ? 4 : 8) * 16;
+    constexpr int nw = 8;  // waves per workgroup (x 16 query rows)
+    const int bq = nw * 16;
     dim3 grid((max_q_len + bq - 1) / bq, head_num, batch);
     const float ks = kv_fp8 ? k_scale : 1.f, vs = kv_fp8 ? v_scale : 1.f;
     if (kv_fp8)
@@ -358,13 +358,8 @@ int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, void *k_cache, vo
 #define LLMIE_FLASH(KV8_, NW_)                                                                                                  \
     prefill_flash_kernel<128, KV8_, NW_><<<grid, NW_ * 64, 0, st>>>(qkv, k_cache, v_cache, out, cum_seqlens, history_len, head_num, \
                                                                     kv_head_num, max_seq_len, layer_off, ks, vs, block_table, max_pages)
-    if (kv_fp8) {
-        if (nw == 4) LLMIE_FLASH(true, 4);
-        else LLMIE_FLASH(true, 8);
-    } else {
-        if (nw == 4) LLMIE_FLASH(false, 4);
-        else LLMIE_FLASH(false, 8);
-    }
+    if (kv_fp8) LLMIE_FLASH(true, 8);
+    else LLMIE_FLASH(false, 8);
 #undef LLMIE_FLASH
     return launch_status("prefill_attention");
 }

@@ -1,5 +1,6 @@
 """Runs the C++ API-mirror drivers (llm-inference-engine_amd/cpp_tests) on the GPU: the reference's unit tests
-replayed through the `launch*` templates, and the layer classes / LlamaModel chat flow against the oracle."""
+replayed through the `launch*` templates, the layer classes / LlamaModel chat flow against the oracle, the call sequences of
+the reference's five examples/cpp drivers, and the reference's own user_entry.cpp built unchanged."""
 import os
 import subprocess
 
@@ -19,3 +20,30 @@ def test_cpp_driver(exe, fp16):
     r = subprocess.run([path] + (["1"] if fp16 else []), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "all passed" in r.stdout and "FAIL" not in r.stdout
+
+
+def test_examples_cpp_call_sequences_replayed():
+    """geometry, constructor arguments, TensorMap keys and input patterns of examples/cpp/*_example.cpp (which themselves need
+    the CUDA toolkit headers and are not built), each checked against the oracle"""
+    path = os.path.join(BIN, "test_examples_replay")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", BIN, "test_examples_replay"])
+    r = subprocess.run([path], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "all passed" in r.stdout and "FAIL" not in r.stdout
+    for name in ("ffn_example", "self_attention_example", "self_decoder_example", "context_attention_example", "context_decoder_example"):
+        assert "replay %s.cpp" % name in r.stdout
+
+
+def test_reference_user_entry_runs_unchanged():
+    """the reference's chat driver, compiled unchanged where the reference tree is present (cpp_tests/Makefile, _ref/user_entry;
+    a force-included shim swaps its checkpoint path for the reference's own dummy weights on a small geometry): one question,
+    then the stop command"""
+    path = os.path.join(BIN, "_ref", "user_entry")
+    if not os.path.exists(path):
+        pytest.skip("built only where the reference tree is present (make -C llm-inference-engine_amd/cpp_tests)")
+    r = subprocess.run([path], input="Hey, are you conscious? Can you talk to me?\ns\n", capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("please input the question") == 2   # one answered round, then the stop command
+    answer = r.stdout.split("please input the question: ")[1]
+    assert answer.startswith(":") and len(answer.strip()) > 1, r.stdout[-500:]
