@@ -159,19 +159,24 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
     int32_t *tickets /* [batch, kv_head_num] zero-initialised arrival counters, or null = separate merge kernel */,
     const QkvSlabs qs /* qs.slab != null: q/k/v come from the split-K partial slabs of the QKV projection (qkv unused) */,
     const float k_scale, const float v_scale /* fp8 cache: stored = e4m3(x / scale); 1 otherwise */,
-    const PagedKv pg /* pg.table != null: k_cache / v_cache are this layer's page pools */) {
+    const PagedKv pg /* pg.table != null: k_cache / v_cache are this layer's page pools */,
+    const int cpw /* chunks of CHUNK tokens one workgroup walks through (online softmax across them): large batches amortise
+                     the per-workgroup prologue / merge (~550 of ~1000 VALU instructions per wave at one chunk) */) {
     using G = AttnGeom<KT, HS, kAttnWaves, kAttnG>;
     using V = typename CacheVec<KT>::type;  // one 16-byte vector of cache elements
     constexpr int N = G::N, LPT = G::LPT, TPW = G::TPW, CHUNK = G::CHUNK;
     constexpr int NT = kAttnWaves * 64;
+    constexpr bool FP8KV = std::is_same<KT, fp8kv_t>::value;
     static_assert(HS % N == 0 && LPT >= 1 && LPT <= 64 && (LPT & (LPT - 1)) == 0, "head size");
 
     const int split = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
     const int step = seq_step(step_dev, step_arg, pg.step_stride, b, max_seq_len);
-    const int t0 = split * CHUNK;
+    const int span = cpw * CHUNK;   // tokens of one workgroup
+    const int t0 = split * span;
     if (t0 >= step) return;  // whole workgroup exits together (also: invalid position)
-    const int t_end = min(step, t0 + CHUNK);
-    const int nsplits = (step + CHUNK - 1) / CHUNK;
+    int tc0 = t0;                             // first token of the chunk being processed
+    int t_end = min(step, tc0 + CHUNK);       // end of that chunk
+    const int nsplits = (step + span - 1) / span;
     const int batch = gridDim.z;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -186,20 +191,24 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
     // scalar loads), so the K/V loads below never depend on a table load.
     constexpr int NPG = CHUNK > KV_PAGE ? CHUNK / KV_PAGE : 1;
     static_assert(CHUNK % KV_PAGE == 0 || KV_PAGE % CHUNK == 0, "chunk vs page size");
-    const int pg0 = t0 / KV_PAGE;
+    int pg0 = 0;
     KT *kbase[NPG], *vbase[NPG];
+    auto set_pages = [&]() {   // of the chunk at tc0
+        pg0 = tc0 / KV_PAGE;
 #pragma unroll
-    for (int j = 0; j < NPG; ++j) {
-        size_t off;
-        if (pg.table) {
-            const int page = pg.table[static_cast<size_t>(b) * pg.max_pages + min(pg0 + j, pg.max_pages - 1)];
-            off = (static_cast<size_t>(page) * kv_head_num + g) * KV_PAGE * HS;
-        } else {
-            off = (static_cast<size_t>(b) * kv_head_num + g) * max_seq_len * HS + static_cast<size_t>(pg0 + j) * KV_PAGE * HS;
+        for (int j = 0; j < NPG; ++j) {
+            size_t off;
+            if (pg.table) {
+                const int page = pg.table[static_cast<size_t>(b) * pg.max_pages + min(pg0 + j, pg.max_pages - 1)];
+                off = (static_cast<size_t>(page) * kv_head_num + g) * KV_PAGE * HS;
+            } else {
+                off = (static_cast<size_t>(b) * kv_head_num + g) * max_seq_len * HS + static_cast<size_t>(pg0 + j) * KV_PAGE * HS;
+            }
+            kbase[j] = k_cache + off;
+            vbase[j] = v_cache + off;
         }
-        kbase[j] = k_cache + off;
-        vbase[j] = v_cache + off;
-    }
+    };
+    set_pages();
     auto krow = [&](int t) { return kbase[NPG == 1 ? 0 : (t / KV_PAGE - pg0)] + static_cast<size_t>(t % KV_PAGE) * HS; };
     auto vrow = [&](int t) { return vbase[NPG == 1 ? 0 : (t / KV_PAGE - pg0)] + static_cast<size_t>(t % KV_PAGE) * HS; };
     KT *kc = kbase[0];  // a readable address of this head (dummy source of the unconditional loads below)
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
     constexpr int ITEMS_PER_HEAD = HS / 4;
     constexpr int LROUNDS = ((REP + 2) * ITEMS_PER_HEAD + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) T qkvlds[(REP + 2) * HS];
-    const bool wg_has_new = t_new >= t0 && t_new < t0 + CHUNK;  // workgroup-uniform
+    const bool wg_has_new = t_new >= t0 && t_new < t0 + span;  // workgroup-uniform
     floatx4 spart[LROUNDS][4];
     half4_t sscale[LROUNDS];
     floatx4 sscalef[LROUNDS];
@@ -265,17 +274,20 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
     // ---- issue every K and V load of this wave's token range ----
     V kv[kAttnG], vv[kAttnG];
     int tok[kAttnG];
+    auto issue_loads = [&]() {   // of the chunk at tc0 (pages set)
 #pragma unroll
-    for (int i = 0; i < kAttnG; ++i) {
-        const int t = t0 + (wave * kAttnG + i) * TPW + sub;
-        tok[i] = t;
-        // rows past the chunk end re-read its last row (masked below); the slot of this step's token is read as it is
-        // (stale, replaced below): every load is unconditional so all 2*G of them are in flight together
-        kv[i] = load_nt(reinterpret_cast<const V *>(krow(min(t, t_end - 1))) + dl);
-    }
+        for (int i = 0; i < kAttnG; ++i) {
+            const int t = tc0 + (wave * kAttnG + i) * TPW + sub;
+            tok[i] = t;
+            // rows past the chunk end re-read its last row (masked below); the slot of this step's token is read as it is
+            // (stale, replaced below): every load is unconditional so all 2*G of them are in flight together
+            kv[i] = load_nt(reinterpret_cast<const V *>(krow(min(t, t_end - 1))) + dl);
+        }
 #pragma unroll
-    for (int i = 0; i < kAttnG; ++i)
-        vv[i] = load_nt(reinterpret_cast<const V *>(vrow(min(tok[i], t_end - 1))) + dl);
+        for (int i = 0; i < kAttnG; ++i)
+            vv[i] = load_nt(reinterpret_cast<const V *>(vrow(min(tok[i], t_end - 1))) + dl);
+    };
+    issue_loads();
     if (qs.slab) {
 #pragma unroll
         for (int lr = 0; lr < LROUNDS; ++lr) {
@@ -333,12 +345,24 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
 #pragma unroll
         for (int e = 0; e < N; ++e) {
             f[e] += qkv_bias ? to_f32(qbias[r][e]) : 0.f;
-            qf[r][e] = f[e] * (scale * k_scale);  // the cache holds k / k_scale
+            qf[r][e] = f[e] * (FP8KV ? scale : scale * k_scale);  // the cache holds k / k_scale (fp8: applied by the conversion)
         }
+    }
+    // e4m3 cache: K.q on packed fp16 -- v_cvt_scalef32_pk_f16_fp8 turns two cache bytes into (k0, k1) * k_scale in one instruction
+    // and v_dot2_f32_f16 adds both products to the fp32 logit: 16 instructions per 16-byte vector instead of 8 conversions + 16
+    // fp32 FMAs.  q (already scaled by 1/sqrt(hs), O(0.1)) is rounded to fp16 for this: 2^-11 relative, far below the cache's
+    // own e4m3 step (2^-4).
+    half2_t qh[FP8KV ? REP : 1][FP8KV ? N / 2 : 1];
+    if constexpr (FP8KV) {
+#pragma unroll
+        for (int r = 0; r < REP; ++r)
+#pragma unroll
+            for (int j = 0; j < N / 2; ++j) qh[r][j] = half2_t{from_f32<half_t>(qf[r][2 * j]), from_f32<half_t>(qf[r][2 * j + 1])};
     }
 
     // the token of this step comes from the qkv buffer / slabs (RoPE, then +bias, as the reference's rope.cu then
     // decoder_self_attention.cu:111-118) and is appended to the cache; computed by every lane, kept by the token's lanes
+    V knv, vnv;   // in the cache's element format: what is stored is what this step attends to
     {
         T kn[N], vn[N];
 #pragma unroll
@@ -363,9 +387,12 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
             kn[e] = qkv_bias ? from_f32<T>(to_f32(kn[e]) + to_f32(kbias[e])) : kn[e];
             vn[e] = qkv_bias ? from_f32<T>(to_f32(vn[e]) + to_f32(vbias[e])) : vn[e];
         }
-        // in the cache's element format: what is stored is what this step attends to
-        const V knv = kv_pack<KT, T, N>(kn, 1.0f / k_scale), vnv = kv_pack<KT, T, N>(vn, 1.0f / v_scale);
+        knv = kv_pack<KT, T, N>(kn, 1.0f / k_scale);
+        vnv = kv_pack<KT, T, N>(vn, 1.0f / v_scale);
+    }
+    auto inject = [&]() {   // chunk at tc0, its loads issued
         bool mine = false;
+        if (t_new >= tc0 && t_new < tc0 + CHUNK) {   // workgroup-uniform: every other chunk skips 8 selects per loaded vector
 #pragma unroll
         for (int i = 0; i < kAttnG; ++i) {
             const bool is_new = tok[i] == t_new;
@@ -380,48 +407,78 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
             kv[i] = __builtin_bit_cast(V, kw);
             vv[i] = __builtin_bit_cast(V, vw);
         }
+        }
         if (mine) {
             reinterpret_cast<V *>(krow(t_new))[dl] = knv;
             reinterpret_cast<V *>(vrow(t_new))[dl] = vnv;
         }
-    }
+    };
+    inject();
 
-    // ---- logits ----
-    float lg[REP][kAttnG];
-    float mx[REP];
-#pragma unroll
-    for (int r = 0; r < REP; ++r) mx[r] = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < kAttnG; ++i) {
-        const bool valid = tok[i] < t_end;
-        float kf[N];
-        kv_to_f32<KT, N>(kv[i], kf);
-#pragma unroll
-        for (int r = 0; r < REP; ++r) {
-            float d = 0.f;
-            if (valid) {
-#pragma unroll
-                for (int e = 0; e < N; ++e) d = fmaf(qf[r][e], kf[e], d);
-            }
-            d = group_sum<LPT>(d);
-            lg[r][i] = valid ? d : -INFINITY;
-            mx[r] = fmaxf(mx[r], lg[r][i]);
-        }
-    }
-    // wave max over the TPW token slots (lanes differing in sub)
+    // running softmax state of this wave over the chunks of the workgroup: maximum (wave-uniform), and per lane the sum of
+    // numerators and the weighted value sums of ITS token slots (reduced across the lanes once, after the last chunk)
+    float mx[REP], acc[REP][N], ls[REP];
 #pragma unroll
     for (int r = 0; r < REP; ++r) {
-#pragma unroll
-        for (int o = LPT; o < 64; o <<= 1) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o, 64));
-    }
-    // ---- softmax numerators and P.V ----
-    float acc[REP][N], ls[REP];
-#pragma unroll
-    for (int r = 0; r < REP; ++r) {
+        mx[r] = -INFINITY;
         ls[r] = 0.f;
 #pragma unroll
         for (int e = 0; e < N; ++e) acc[r][e] = 0.f;
     }
+    auto accumulate = [&](const bool first) {   // chunk at tc0, its vectors landed and patched
+    // ---- logits ----
+    float lg[REP][kAttnG];
+    float cm[REP];
+#pragma unroll
+    for (int r = 0; r < REP; ++r) cm[r] = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < kAttnG; ++i) {
+        const bool valid = tok[i] < t_end;
+        float kf[FP8KV ? 1 : N];
+        half2_t kh[FP8KV ? N / 2 : 1];
+        if constexpr (FP8KV) {
+            const uint4_t kw = __builtin_bit_cast(uint4_t, kv[i]);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                kh[2 * w] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(kw[w]), k_scale, false);
+                kh[2 * w + 1] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(kw[w]), k_scale, true);
+            }
+        } else {
+            kv_to_f32<KT, N>(kv[i], kf);
+        }
+#pragma unroll
+        for (int r = 0; r < REP; ++r) {
+            float d = 0.f;
+            if (valid) {
+                if constexpr (FP8KV) {
+#pragma unroll
+                    for (int j = 0; j < N / 2; ++j) d = __builtin_amdgcn_fdot2(kh[j], qh[r][j], d, false);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < N; ++e) d = fmaf(qf[r][e], kf[e], d);
+                }
+            }
+            d = group_sum<LPT>(d);
+            lg[r][i] = valid ? d : -INFINITY;
+            cm[r] = fmaxf(cm[r], lg[r][i]);
+        }
+    }
+    // wave max over the TPW token slots (lanes differing in sub), then the running maximum; what was accumulated under the old
+    // maximum is rescaled (nothing to rescale in a workgroup's first chunk)
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+#pragma unroll
+        for (int o = LPT; o < 64; o <<= 1) cm[r] = fmaxf(cm[r], __shfl_xor(cm[r], o, 64));
+        const float mnew = fmaxf(mx[r], cm[r]);
+        if (!first) {
+            const float f = (mx[r] == -INFINITY) ? 0.f : __expf(mx[r] - mnew);
+            ls[r] *= f;
+#pragma unroll
+            for (int e = 0; e < N; ++e) acc[r][e] *= f;
+        }
+        mx[r] = mnew;
+    }
+    // ---- softmax numerators and P.V ----
 #pragma unroll
     for (int i = 0; i < kAttnG; ++i) {
         const bool valid = tok[i] < t_end;
@@ -435,6 +492,23 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
 #pragma unroll
                 for (int e = 0; e < N; ++e) acc[r][e] = fmaf(p, vf[e], acc[r][e]);
             }
+        }
+    }
+    };
+    accumulate(true);
+    // the workgroup's further chunks: same loads, same arithmetic, the prologue above paid once.  e4m3 cache only: there the
+    // fixed work is ~550 of ~1000 VALU instructions per wave and batch 32 x ctx 2048 went from 130 to 98 us per layer (4.1 ->
+    // 5.5 TB/s); the fp16 cache streams at 6.2-6.3 TB/s with one chunk per workgroup and the loop's longer register live ranges
+    // (146 -> 177 VGPRs, two workgroups per CU instead of three) cost 2.5 us per launch at ctx 128, so it is compiled out there.
+    if constexpr (FP8KV) {
+        for (int c = 1; c < cpw; ++c) {
+            tc0 += CHUNK;
+            if (tc0 >= step) break;   // workgroup-uniform
+            t_end = min(step, tc0 + CHUNK);
+            set_pages();
+            issue_loads();
+            inject();
+            accumulate(false);
         }
     }
 #pragma unroll
@@ -608,15 +682,21 @@ static void launch_split(const T *qkv, const T *bias, KT *kc, KT *vc, float *par
                          int max_splits_ws, const float2 *rope, int rot_dim, int32_t *tickets, const QkvSlabs &qs,
                          KvScale ks, PagedKv pg, hipStream_t st) {
     const int bound = step_dev ? max_seq_len : step;
+    // chunks per workgroup: a function of the batch geometry ONLY (not of the step: the host-step and the device-step form of
+    // one call must chunk alike), 1 while the grid needs every chunk as its own workgroup, up to 4 for large batches
+    int cpw = 1;
+    if constexpr (!std::is_same<KT, T>::value) {   // (e4m3 cache only, see the kernel)
+        while (cpw < 4 && batch * kv_head_num >= 256 * cpw) cpw *= 2;
+    }
     int CHUNK, splits;
 #define LLMIE_ATTN_LAUNCH(NWV_, GL_)                                                                                   \
     do {                                                                                                                \
-        CHUNK = AttnGeom<KT, HS, NWV_, GL_>::CHUNK;                                                                     \
+        CHUNK = cpw * AttnGeom<KT, HS, NWV_, GL_>::CHUNK;                                                               \
         splits = (bound + CHUNK - 1) / CHUNK;                                                                           \
         dim3 grid(splits, kv_head_num, batch);                                                                          \
         decode_attn_split_kernel<T, HS, REP, NWV_, GL_, KT><<<grid, NWV_ * 64, 0, st>>>(                                \
             qkv, bias, kc, vc, part, out, head_num, kv_head_num, max_seq_len, step, step_dev, max_splits_ws, rope, rot_dim, \
-            tickets, qs, ks.k, ks.v, pg);                                                                               \
+            tickets, qs, ks.k, ks.v, pg, cpw);                                                                          \
     } while (0)
     LLMIE_ATTN_LAUNCH(4, 8);   // 4 waves, 8 K + 8 V loads in flight per lane (8 waves x 8 and 4 x 4 measured slower, round 1)
 #undef LLMIE_ATTN_LAUNCH
