@@ -100,16 +100,18 @@ def sq(d, out, cmd, subs):
                 "#   (8 XCDs x 4), so SQ_BUSY_CYCLES / 32 = kernel duration in shader cycles and x 1024 SIMDs = all SIMD cycles;\n"
                 "#   wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES;\n"
                 "#   issue_stall_frac = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES; lds_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE\n")
-        f.write("Name,Grid,Launches," + ",".join(names) + ",mfma_busy_frac,wait_frac,issue_stall_frac,lds_conflict_frac\n")
+        f.write("# valu_busy_frac = SQ_ACTIVE_INST_VALU (quad-cycles, summed over waves) * 4 / (SQ_BUSY_CYCLES / 32 * 1024 SIMDs)\n")
+        f.write("Name,Grid,Launches," + ",".join(names) + ",mfma_busy_frac,wait_frac,issue_stall_frac,lds_conflict_frac,valu_busy_frac\n")
         for key in sorted(acc, key=lambda k: -sum(acc[k].get("SQ_WAVE_CYCLES", [0]))):
             v = {c: sum(x) / len(x) for c, x in acc[key].items()}
             n_l = max(len(x) for x in acc[key].values())
 
             def ratio(a, b, k=1.0):
                 return "%.4f" % (v[a] / (v[b] * k)) if a in v and b in v and v[b] > 0 else ""
-            f.write('"%s",%d,%d,%s,%s,%s,%s,%s\n' % (short(key[0]), key[1], n_l, ",".join("%.0f" % v.get(c, 0.0) for c in names),
-                                                   ratio("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", 32.0), ratio("SQ_WAIT_ANY", "SQ_WAVE_CYCLES"),
-                                                   ratio("SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES"), ratio("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE")))
+            f.write('"%s",%d,%d,%s,%s,%s,%s,%s,%s\n' % (short(key[0]), key[1], n_l, ",".join("%.0f" % v.get(c, 0.0) for c in names),
+                                                      ratio("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", 32.0), ratio("SQ_WAIT_ANY", "SQ_WAVE_CYCLES"),
+                                                      ratio("SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES"), ratio("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"),
+                                                      ratio("SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", 8.0)))
     print("wrote", out)
 
 
