@@ -385,7 +385,13 @@ int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, void *hidde
                           int max_q_len, void *workspace, size_t workspace_bytes, llmie_stream stream);
 
 /* LM head + top-k + sampling tail (llama.cpp:247-318): final RMSNorm(gamma) -> logits =
- * x . lm_head[V,H]^T -> top-K -> sample.  logits[bs,V] and topk buffers caller-owned. */
+ * x . lm_head[V,H]^T -> top-K -> sample.  logits[bs,V] and topk buffers caller-owned.
+ * `hidden` is CLOBBERED and its content afterwards is unspecified: the fused-norm GEMV form (fp16, small batches) leaves it
+ * as it was, every other form RMS-normalises it in place as the reference does (llama.cpp:247) -- do not read it, and do not
+ * call this twice on one buffer.  Candidates the top-k could not fill (NaN logits) are skipped by the sampler; a row without
+ * any valid candidate emits end_id and sets finished.  In fp16 the sampler keeps exp(v - max) in fp32 where sampling.cu:31
+ * rounds it to T first: the chosen token can differ at a bin edge (parity unpinned there, the cuRAND stream is not reproducible
+ * either). */
 int llmie_lm_head_sample(llmie_decoder *dec, void *hidden /* [bs,H]; clobbered (may be normalised in place) */,
                          const void *final_norm_gamma, const llmie_matrix *lm_head,
                          llmie_weight_format lm_fmt, void *logits,

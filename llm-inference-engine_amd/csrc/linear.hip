@@ -269,24 +269,24 @@ int linear_splitk_partial(int wbits, const void *x, const void *W, int M, int K,
         const int wn = p.wn, ks = p.ks, per = p.per;
         const int mtiles = (N + 64 * wn - 1) / (64 * wn);
         float *mslab = ws.p;
-    static bool attr_set = false;
-        if (!attr_set) {
+    static const bool attr_set = [] {   // once per process, thread-safe (function-local static initialisation)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<false, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 16384);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<true, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 16384);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<false, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 16384);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<true, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 16384);
-            attr_set = true;
-        }
+            return true;
+        }();
+        (void)attr_set;
         const dim3 mgrid(mtiles * ks);
         if (mid64) {
-            static bool attr64 = false;
-            if (!attr64) {
+            static const bool attr64 = [] {   // once per process, thread-safe (function-local static initialisation)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<false, 4, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 40960);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<true, 4, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 40960);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<false, 2, 6, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 24576);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<true, 2, 6, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 24576);
-                attr64 = true;
-            }
+                return true;
+            }();
+            (void)attr64;
             if (wn == 4) {
                 if (fp8) mid_splitk_kernel<true, 4, 4, 64><<<mgrid, 512, 4 * 40960, st>>>(x, W, mslab, M, N, K, ks, per);
                 else mid_splitk_kernel<false, 4, 4, 64><<<mgrid, 512, 4 * 40960, st>>>(x, W, mslab, M, N, K, ks, per);
@@ -512,12 +512,12 @@ template <bool FP8, bool EPI, int WN>
 static void gemm256_launch_t(const void *x, const void *W, half_t *y, int M, int N, int K, const half_t *bias, const half_t *residual,
                              const float *xscale, const float *wscale, hipStream_t st, int ldc = 0) {
     constexpr int lds_bytes = 2 * (2 + WN / 2) * 128 * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static const bool attr_set = [] {   // once per process, thread-safe (function-local static initialisation)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm256_kernel<FP8, EPI, WN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        attr_set = true;
-    }
+        return true;
+    }();
+    (void)attr_set;
     const int tm = (M + 255) / 256, tn = (N + 64 * WN - 1) / (64 * WN);
     gemm256_kernel<FP8, EPI, WN><<<tm * tn, 512, lds_bytes, st>>>(x, W, y, M, N, K, bias, residual, tn, xscale, wscale, ldc, g256_group_m());
 }
@@ -531,14 +531,14 @@ bool gemm256_swiglu_fills(int M, int two_inter) {
 void gemm256_swiglu_launch(bool fp8, const void *x, const void *W, half_t *y, int M, int two_inter, int K, const float *xscale,
                            const float *wscale, hipStream_t st) {
     constexpr int lds_bytes = 2 * 4 * 128 * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static const bool attr_set = [] {   // once per process, thread-safe (function-local static initialisation)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm256_kernel<false, false, 4, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm256_kernel<true, false, 4, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        attr_set = true;
-    }
+        return true;
+    }();
+    (void)attr_set;
     const int tm = (M + 255) / 256, tn = (two_inter / 2 + 127) / 128;
     if (fp8)
         gemm256_kernel<true, false, 4, true><<<tm * tn, 512, lds_bytes, st>>>(x, W, y, M, two_inter, K, nullptr, nullptr, tn, xscale, wscale, 0, g256_group_m());

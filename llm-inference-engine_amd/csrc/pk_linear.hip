@@ -122,11 +122,11 @@ size_t pk_slab_floats(int wf, int M, int K, int N) {
 template <int MT, int WF, int EPI, int XM> static void pk_launch_x(const PkArgs &a, const PkPlan &p, hipStream_t st) {
     // reduction slots + per-wave DMA ring + epilogue tables + norm staging (pk_lds); the opt-in limit is registered once
     constexpr int lds_max = 160 * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static const bool attr_set = [] {   // once per process, thread-safe (function-local static initialisation)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pk_mfma_kernel<MT, WF, EPI, XM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-        attr_set = true;
-    }
+        return true;
+    }();
+    (void)attr_set;
     const int lds = pk_lds(MT, EPI, a.gamma ? (a.pre_bias ? 2 * a.K : a.K) : 0, EPI == PK_EPI_PLAIN && a.residual != nullptr).total;
     pk_mfma_kernel<MT, WF, EPI, XM><<<dim3(p.gx, p.KS), 512, lds, st>>>(a);
 }

@@ -23,6 +23,7 @@ __global__ __launch_bounds__(256) void rope_decode_kernel(T *__restrict__ qkv, i
     const int half = head_size >> 1;
     const int nrot = min(half, rotary_dim >> 1);
     const int pos_i = (step_dev ? *step_dev : step) - 1;
+    if (pos_i < 0) return;   // a corrupt device-resident step: leave the rows alone (whole workgroup)
     const float pos = static_cast<float>(pos_i);
     for (int d = threadIdx.x; d < nrot; d += 256) rope_cis(d, rotary_dim, base, pos, cs[2 * d], cs[2 * d + 1]);
     __syncthreads();

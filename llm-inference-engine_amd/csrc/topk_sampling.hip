@@ -182,16 +182,27 @@ __global__ __launch_bounds__(64) void sampling_kernel(const int32_t *__restrict_
     const int step = step_dev ? *step_dev : step_arg;
     const int32_t *id = topk_id + static_cast<size_t>(b) * K;
     const T *val = topk_val + static_cast<size_t>(b) * K;
-    const float v0 = to_f32(val[0]);
-    float sum = 0.f;
-    for (int i = 0; i < K; ++i) sum += expf(to_f32(val[i]) - v0);
-    float thr = uniform_philox(static_cast<uint32_t>(step), static_cast<uint32_t>(b)) * sum;
-    int chosen = id[0] % vocab;
-    for (int i = 0; i < K; ++i) {
-        thr -= expf(to_f32(val[i]) - v0);
-        if (thr < 0.f) {
-            chosen = id[i] % vocab;
-            break;
+    // candidates with id < 0 are list slots the top-k never filled (NaN logits are never "better" than anything, sampling.cu has
+    // no such case because cub's sort keeps NaNs): they are skipped; a row with no valid candidate at all ends its sequence
+    // (end_id, finished) instead of emitting token -1
+    int first = -1;
+    for (int i = 0; i < K && first < 0; ++i)
+        if (id[i] >= 0) first = i;
+    int chosen = end_id;
+    if (first >= 0) {
+        const float v0 = to_f32(val[first]);
+        float sum = 0.f;
+        for (int i = first; i < K; ++i)
+            if (id[i] >= 0) sum += expf(to_f32(val[i]) - v0);
+        float thr = uniform_philox(static_cast<uint32_t>(step), static_cast<uint32_t>(b)) * sum;
+        chosen = id[first] % vocab;
+        for (int i = first; i < K; ++i) {
+            if (id[i] < 0) continue;
+            thr -= expf(to_f32(val[i]) - v0);
+            if (thr < 0.f) {
+                chosen = id[i] % vocab;
+                break;
+            }
         }
     }
     out_id[b] = chosen;
