@@ -38,6 +38,7 @@ struct llmie_decoder {
     // activations between the packed kernels in the x32 layout, and the split-K slabs of the down projection
     struct PackedLayer {
         const unsigned char *qkv, *o, *gate_up, *down;
+        const void *sc[4];   // int4: packed group-scale images of the four matrices (else null: the caller's row scales are used)
     };
     std::vector<PackedLayer> packed;
     int pk_wf = 0;                    // PKF_* of the engine's weight format, 0 = no packed path
@@ -108,12 +109,27 @@ struct Carve {
     }
 };
 
+// Largest decode batch on the GEMV path.  Its dot products are VALU work that grows with the batch while a packed-weight
+// (MFMA) step is nearly flat, so the switch sits at the measured crossover (MI355X, 7B, ctx 512, tokens/s GEMV vs packed,
+// round 2): fp16 b3 924 / 905, b4 1140 / 1186; int8 b2 918 / 828, b3 1172 / 1211; fp8 b2 804 / 720, b3 1009 / 1044;
+// int4 (ctx 2048) b1 460 / 442, b2 710 / 812.
+static int gemv_max_batch(llmie_weight_format wfmt) {
+    switch (wfmt) {
+        case LLMIE_W_F16: return 3;
+        case LLMIE_W_INT8: return 2;
+        case LLMIE_W_FP8: return 2;
+        case LLMIE_W_INT4: return 1;
+        default: return 4;
+    }
+}
+
 // weight format / shapes the packed batch path covers; max rows it will be asked for
 static int packed_wf(const llmie_decoder_config *c) {
     if (c->dtype != LLMIE_F16) return 0;
-    const int wf = c->wfmt == LLMIE_W_F16 ? PKF_F16 : (c->wfmt == LLMIE_W_INT8 ? PKF_I8 : (c->wfmt == LLMIE_W_FP8 ? PKF_FP8 : 0));
+    const int wf = c->wfmt == LLMIE_W_F16 ? PKF_F16
+                   : (c->wfmt == LLMIE_W_INT8 ? PKF_I8 : (c->wfmt == LLMIE_W_FP8 ? PKF_FP8 : (c->wfmt == LLMIE_W_INT4 && c->int4_group == 128 ? PKF_I4 : 0)));
     // batches up to the GEMV crossover never take the packed path: no second copy of the weights for such engines
-    const int gemv_max = c->wfmt == LLMIE_W_FP8 ? 3 : 4;
+    const int gemv_max = gemv_max_batch(c->wfmt);
     if (!wf || c->max_batch <= gemv_max) return 0;
     const int H = c->head_num * c->head_size, QKV = (c->head_num + 2 * c->kv_head_num) * c->head_size, I = c->inter_size;
     const int m = c->max_batch < 32 ? c->max_batch : 32;
@@ -132,10 +148,11 @@ static PackedCarve packed_carve(const llmie_decoder_config *c, int wf) {
     PackedCarve p{};
     if (!wf) return p;
     const int H = c->head_num * c->head_size, QKV = (c->head_num + 2 * c->kv_head_num) * c->head_size, I = c->inter_size;
-    p.per_layer[0] = align_up(pk_packed_bytes(wf, QKV, H, 0));
-    p.per_layer[1] = align_up(pk_packed_bytes(wf, H, H, 0));
-    p.per_layer[2] = align_up(pk_packed_bytes(wf, 2 * I, H, 1));
-    p.per_layer[3] = align_up(pk_packed_bytes(wf, H, I, 0));
+    // (each matrix: weight image, then -- int4 -- its group-scale image)
+    p.per_layer[0] = align_up(pk_packed_bytes(wf, QKV, H, 0)) + align_up(pk_packed_scale_bytes(wf, QKV, H, 0));
+    p.per_layer[1] = align_up(pk_packed_bytes(wf, H, H, 0)) + align_up(pk_packed_scale_bytes(wf, H, H, 0));
+    p.per_layer[2] = align_up(pk_packed_bytes(wf, 2 * I, H, 1)) + align_up(pk_packed_scale_bytes(wf, 2 * I, H, 1));
+    p.per_layer[3] = align_up(pk_packed_bytes(wf, H, I, 0)) + align_up(pk_packed_scale_bytes(wf, H, I, 0));
     p.layer_bytes = p.per_layer[0] + p.per_layer[1] + p.per_layer[2] + p.per_layer[3];
     p.hx = align_up(static_cast<size_t>(H) * 64);
     p.actx = align_up(static_cast<size_t>(I) * 64);
@@ -280,11 +297,14 @@ extern "C" llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg, 
             unsigned char *q = pb + static_cast<size_t>(l) * pc.layer_bytes;
             unsigned char *po = q + pc.per_layer[0], *pg = po + pc.per_layer[1], *pd = pg + pc.per_layer[2];
             const llmie_layer_weights &w = layers[l];
-            prc = pk_pack(d->pk_wf, w.qkv.data, nullptr, q, nullptr, QKV, H, 0, nullptr);
-            if (!prc) prc = pk_pack(d->pk_wf, w.o.data, nullptr, po, nullptr, H, H, 0, nullptr);
-            if (!prc) prc = pk_pack(d->pk_wf, w.gate_up.data, nullptr, pg, nullptr, 2 * I, H, 1, nullptr);
-            if (!prc) prc = pk_pack(d->pk_wf, w.down.data, nullptr, pd, nullptr, H, I, 0, nullptr);
-            d->packed[l] = llmie_decoder::PackedLayer{q, po, pg, pd};
+            const bool i4 = d->pk_wf == PKF_I4;
+            unsigned char *sq = q + align_up(pk_packed_bytes(d->pk_wf, QKV, H, 0)), *so = po + align_up(pk_packed_bytes(d->pk_wf, H, H, 0));
+            unsigned char *sg = pg + align_up(pk_packed_bytes(d->pk_wf, 2 * I, H, 1)), *sd = pd + align_up(pk_packed_bytes(d->pk_wf, H, I, 0));
+            prc = pk_pack(d->pk_wf, w.qkv.data, i4 ? w.qkv.scale : nullptr, q, i4 ? sq : nullptr, QKV, H, 0, nullptr);
+            if (!prc) prc = pk_pack(d->pk_wf, w.o.data, i4 ? w.o.scale : nullptr, po, i4 ? so : nullptr, H, H, 0, nullptr);
+            if (!prc) prc = pk_pack(d->pk_wf, w.gate_up.data, i4 ? w.gate_up.scale : nullptr, pg, i4 ? sg : nullptr, 2 * I, H, 1, nullptr);
+            if (!prc) prc = pk_pack(d->pk_wf, w.down.data, i4 ? w.down.scale : nullptr, pd, i4 ? sd : nullptr, H, I, 0, nullptr);
+            d->packed[l] = llmie_decoder::PackedLayer{q, po, pg, pd, {i4 ? sq : nullptr, i4 ? so : nullptr, i4 ? sg : nullptr, i4 ? sd : nullptr}};
         }
         unsigned char *tail = pb + pc.layer_bytes * cfg->num_layers;
         d->hx = reinterpret_cast<half_t *>(tail);
@@ -446,7 +466,7 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
     // GEMV form up to gemv_max rows (its dot products are VALU work that grows with the batch), MFMA split-K above
     // measured crossover on MI355X (7B, ctx 512, tokens/s GEMV vs split-K): fp16 b4 1157/1143, b6 1496/1592; int8 b4 1416/1404,
     // b6 1672/1962; fp8 b3 947/944, b4 1127/1213; int4 b2 796/745, b3 896/1074
-    const int gemv_max = fp8 ? 3 : (wbits == 4 ? 2 : 4);
+    const int gemv_max = gemv_max_batch(c.wfmt);
     static const int batch_fused_off = getenv("LLMIE_NO_FUSED_BATCH") ? 1 : 0;
     const bool int4_ok = wbits == 4 && c.int4_group == 128 && batch <= 64;  // int4 MFMA form: group-128 scales, 64 rows per pass
     const bool batch_path_ok = !batch_fused_off && c.dtype == LLMIE_F16 && (wbits == 16 || wbits == 8 || int4_ok || fp8) && hs_ok &&
@@ -524,18 +544,18 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
             const llmie_decoder::PackedLayer &pw = dec->packed[l];
             const bool first = l == 0, last = l + 1 == c.num_layers;
             // layer 0 reads the caller's row-major hidden state; from its output projection on the residual stream lives in hx
-            TIMED(LLMIE_OP_QKV_GEMM, pk_linear(wf, first ? hh : dec->hx, pw.qkv, w.qkv.scale, qkvb, batch, H, QKV, PKE_PLAIN, first ? 0 : PKX_X,
+            TIMED(LLMIE_OP_QKV_GEMM, pk_linear(wf, first ? hh : dec->hx, pw.qkv, pw.sc[0] ? pw.sc[0] : w.qkv.scale, qkvb, batch, H, QKV, PKE_PLAIN, first ? 0 : PKX_X,
                                                nullptr, static_cast<const half_t *>(w.attn_norm_gamma), nullptr, c.rms_eps, nullptr, 0, st));
             TIMED(LLMIE_OP_MHA, decoder_mha_rope(dec->qkv, w.qkv.bias, k_cache, v_cache, dec->mhax, l, batch, c.head_num, c.kv_head_num,
                                                  c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws, dec->attn_ws_bytes,
                                                  dec->rope_table, c.rotary_dim, nullptr, dt, st, nullptr, nullptr, kv8, k_scale, v_scale,
                                                  dec->page_table, dec->max_pages, dec->num_pages, dec->ragged, 1));
-            TIMED(LLMIE_OP_O_GEMM, pk_linear(wf, dec->mhax, pw.o, w.o.scale, dec->hx, batch, H, H, PKE_PLAIN, PKX_X | PKX_Y | (first ? 0 : PKX_RES),
+            TIMED(LLMIE_OP_O_GEMM, pk_linear(wf, dec->mhax, pw.o, pw.sc[1] ? pw.sc[1] : w.o.scale, dec->hx, batch, H, H, PKE_PLAIN, PKX_X | PKX_Y | (first ? 0 : PKX_RES),
                                              first ? hh : dec->hx, nullptr, nullptr, 0.f, nullptr, 0, st));
-            TIMED(LLMIE_OP_GATE_UP_SWIGLU, pk_linear(wf, dec->hx, pw.gate_up, w.gate_up.scale, dec->actx, batch, H, 2 * I, PKE_SWIGLU, PKX_X | PKX_Y,
+            TIMED(LLMIE_OP_GATE_UP_SWIGLU, pk_linear(wf, dec->hx, pw.gate_up, pw.sc[2] ? pw.sc[2] : w.gate_up.scale, dec->actx, batch, H, 2 * I, PKE_SWIGLU, PKX_X | PKX_Y,
                                                      nullptr, static_cast<const half_t *>(w.ffn_norm_gamma), static_cast<const half_t *>(w.o.bias),
                                                      c.rms_eps, nullptr, 0, st));
-            TIMED(LLMIE_OP_DOWN_GEMM, pk_linear(wf, dec->actx, pw.down, w.down.scale, last ? hh : dec->hx, batch, I, H, PKE_PLAIN,
+            TIMED(LLMIE_OP_DOWN_GEMM, pk_linear(wf, dec->actx, pw.down, pw.sc[3] ? pw.sc[3] : w.down.scale, last ? hh : dec->hx, batch, I, H, PKE_PLAIN,
                                                 PKX_X | PKX_RES | (last ? 0 : PKX_Y), dec->hx, nullptr, nullptr, 0.f, dec->pk_slab,
                                                 dec->pk_slab_floats, st));
         }

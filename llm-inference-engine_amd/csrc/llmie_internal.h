@@ -76,6 +76,7 @@ enum : int { PKF_F16 = 16, PKF_I8 = 8, PKF_I4 = 4, PKF_FP8 = 108 };             
 enum : int { PKE_PLAIN = 0, PKE_SWIGLU = 1 };
 enum : int { PKX_X = 1, PKX_Y = 2, PKX_RES = 4 };                                    // operands in the x32 activation layout
 size_t pk_packed_bytes(int wf, int N, int K, int swiglu);
+size_t pk_packed_scale_bytes(int wf, int N, int K, int swiglu);   // int4: the group-scale image beside the weight image (else 0)
 int pk_pack(int wf, const void *src, const void *src_scale, void *dst, void *dst_scale, int N, int K, int swiglu, hipStream_t st);
 bool pk_eligible(int wf, int M, int K, int N, int epi);
 size_t pk_slab_floats(int wf, int M, int K, int N);

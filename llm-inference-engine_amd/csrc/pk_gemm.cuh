@@ -126,6 +126,10 @@ __device__ __forceinline__ void pk_gload16_s(uint4_t &dst, const unsigned voff, 
 __device__ __forceinline__ void pk_dma16_nt(const unsigned voff, const void *sbase, const unsigned lds_dst) {
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
+// 256 bytes per wave (4 per lane): the int4 group-scale records of one tile slice
+__device__ __forceinline__ void pk_dma4(const unsigned voff, const void *sbase, const unsigned lds_dst) {
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
 __device__ __forceinline__ void pk_gload16(uint4_t &dst, const void *p) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
@@ -194,7 +198,6 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
     constexpr int NPAR = TPI == 1 ? 2 : 1;               // reduction-slot parities (SwiGLU: one slot set + a second barrier per unit)
     constexpr int D = pk_ring_depth(EPI);
     constexpr int XPB = SPB * MT;                        // activation fragments (= loads) per block
-    static_assert(XBLK % 2 == 0, "two alternating block registers per tile");
     typedef __attribute__((address_space(3))) void *lptr_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char pk_smem[];
     const bool has_res = EPI == PK_EPI_PLAIN && a.residual != nullptr;
@@ -221,8 +224,14 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
     const int iters = (a.units - static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
     const int L = iters * TPI;
     auto unit_at = [&](int it) { return it * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x); };
-    // this wave's block stream: element k = (tile i = k / cnt, block u = k % cnt), T = L * cnt elements
-    const int T = L * cnt;
+    // this wave's block stream: element k = (tile i = k / ept, block u = k % ept), T = L * ept elements.
+    // int4 (group-128 scales, KB = 128 = one group per block): every tile's blocks are preceded by ONE more stream element, the
+    // [blocks][16 rows] fp16 scale records of the wave's slice (<= 4 x 32 bytes, fetched as a 256-byte DMA into a ring slot of
+    // its own) -- a ring element like any other, so every counted wait of the loop stays what it is.
+    constexpr bool I4 = WF == PK_I4;
+    constexpr int SE = I4 ? 1 : 0;
+    const int ept = cnt > 0 ? cnt + SE : 0;
+    const int T = L * ept;
     unsigned char *ring = ring_all + wave * (D * 1024);
     const unsigned woff = lane * 16;
     const unsigned ring_lds = static_cast<unsigned>(reinterpret_cast<size_t>((lptr_t)ring));   // LDS byte address, wave-uniform
@@ -233,14 +242,23 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
     const long step_in = static_cast<long>(tile_bytes) - static_cast<long>(cnt) * 1024;
     const long step_unit = static_cast<long>(static_cast<size_t>(gridDim.x) * TPI - (TPI - 1)) * static_cast<long>(tile_bytes) - static_cast<long>(cnt) * 1024;
     const unsigned char *src = a.Wp + (static_cast<size_t>(unit_at(0)) * TPI * a.nblk + blk0) * 1024;
-    int ri = 0, ru = 0;   // (tile, block) of the next stream element to fetch
+    // int4: the scale image [tiles][nblk][16] fp16 runs beside the weight image (a.scale), 32 bytes per block
+    const unsigned char *ssrc = I4 ? reinterpret_cast<const unsigned char *>(a.scale) + (static_cast<size_t>(unit_at(0)) * TPI * a.nblk + blk0) * 32 : nullptr;
+    const long sstep_in = static_cast<long>(a.nblk) * 32;
+    const long sstep_unit = static_cast<long>(static_cast<size_t>(gridDim.x) * TPI - (TPI - 1)) * static_cast<long>(a.nblk) * 32;
+    int ri = 0, ru = 0;   // (tile, element inside the tile) of the next stream element to fetch
     auto dma_next = [&](const unsigned slot_bytes) {
-        pk_dma16_nt(woff, src, ring_lds + slot_bytes);
-        src += 1024;
-        if (++ru == cnt) {
+        if (I4 && ru == 0) {
+            pk_dma4(lane * 4, ssrc, ring_lds + slot_bytes);
+        } else {
+            pk_dma16_nt(woff, src, ring_lds + slot_bytes);
+            src += 1024;
+        }
+        if (++ru == ept) {
             ru = 0;
             ++ri;
             src += (TPI == 2 && (ri & 1)) ? step_in : step_unit;
+            if constexpr (I4) ssrc += (TPI == 2 && (ri & 1)) ? sstep_in : sstep_unit;
         }
     };
 
@@ -602,6 +620,20 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
     wq[0] = uint4_t{0u, 0u, 0u, 0u};
     wq[1] = wq[0];
     if (T > 0) wq[0] = lds_block(0);
+    floatx4 scf[I4 ? XBLK : 1];   // int4: group scales of the current tile's blocks, rows 4 q + e of the tile
+    // the scale element at ring slot `slot` (landed): records [block][16 rows] fp16, this lane takes rows 4 q .. 4 q + 3
+    auto read_scales = [&](const unsigned slot_bytes) {
+        if constexpr (I4) {
+            half4_t raw[XBLK];
+#pragma unroll
+            for (int u = 0; u < XBLK; ++u)
+                raw[u] = *reinterpret_cast<const half4_t *>(ring_all + wave * (D * 1024) + slot_bytes + u * 32 + q * 8);
+#pragma unroll
+            for (int u = 0; u < XBLK; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) scf[u][e] = to_f32(raw[u][e]);   // (the conversions make the reads complete before the refill)
+        }
+    };
     auto mma_into = [&](floatx4 (&acc)[MT], auto u_tag, const uint4_t &w, const half8_t (&af)[(FP8 || WF == PK_F16) ? 1 : SPB]) {
         constexpr int u = decltype(u_tag)::value;
         if constexpr (FP8) {
@@ -618,6 +650,20 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
 #pragma unroll
             for (int t = 0; t < MT; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, w), xfrag(xw[u][0][t]), acc[t], 0, 0, 0);
+        } else if constexpr (I4) {
+            // one group per block: the block's 4 k-steps accumulate from zero and enter the running sums through the group scales
+            // of the lane's 4 weight rows (D rows 4 q + e): 4 FMAs per row tile instead of 16 packed multiplies of the A fragments
+            floatx4 tmp[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) tmp[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < SPB; ++s)
+#pragma unroll
+                for (int t = 0; t < MT; ++t) tmp[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s], xfrag(xw[u][s][t]), tmp[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t][e] = fmaf(tmp[t][e], scf[u][e], acc[t][e]);
         } else {
 #pragma unroll
             for (int s = 0; s < SPB; ++s)
@@ -632,54 +678,71 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
             for (int s = 0; s < SPB; ++s) af[s] = pk_afrag<WF>(w, s);
         }
     };
+    // One tile = ept stream elements: (int4: the scale element, then) the wave's blocks.  Step e of a tile works on the element in
+    // wq[e & 1] and fetches its successor into the other register.
     auto tile_blocks = [&]() {
-        if (cnt == XBLK && kk + XBLK + D <= T) {
-            // steady tile: every block's refill (element + D) and successor (element + 1) exist and are D - 1 deep
-            pk_static_for<XBLK>([&](auto u_tag) {
-                constexpr int u = decltype(u_tag)::value;
-                uint4_t &w = wq[u & 1];
-                pk_landed(w);   // its LDS read (issued a block ago) has returned: the slot may be overwritten by the refill below
+        constexpr int STEPS = XBLK + SE;
+        if (cnt == XBLK && kk + STEPS + D <= T) {
+            // steady tile: every element's refill (element + D) and successor (element + 1) exist and are D - 1 deep
+            pk_static_for<STEPS>([&](auto e_tag) {
+                constexpr int e = decltype(e_tag)::value;
+                uint4_t &w = wq[e & 1];
+                pk_landed(w);   // its LDS read (issued a step ago) has returned: the slot may be overwritten by the refill below
                 // successor first: its LDS latency hides behind this block's de-quantisation and MFMAs (element + D is not
                 // issued yet: D - 2 younger DMAs)
                 const unsigned nsb = next_slot(sb);
                 pk_vmwait<D - 2>();
-                wq[(u + 1) & 1] = lds_block(nsb);
-                half8_t af[(FP8 || WF == PK_F16) ? 1 : SPB];
-                dequant(w, af);
-                dma_next(sb);
-                sb = nsb;
-                mma_block(u_tag, w, af);
-            });
-            kk += XBLK;
-        } else if (kk + cnt + D <= T) {
-            // the same steady body for a wave that owns fewer blocks than its register slice holds (K split over workgroups:
-            // the 7B down projection gives its waves 5 or 6 of 8)
-            pk_static_for<XBLK>([&](auto u_tag) {
-                constexpr int u = decltype(u_tag)::value;
-                if (u < cnt) {   // wave-uniform
-                    uint4_t &w = wq[u & 1];
-                    pk_landed(w);
-                    const unsigned nsb = next_slot(sb);
-                    pk_vmwait<D - 2>();
-                    wq[(u + 1) & 1] = lds_block(nsb);
+                wq[(e + 1) & 1] = lds_block(nsb);
+                if constexpr (I4 && e == 0) {
+                    read_scales(sb);
+                    dma_next(sb);
+                    sb = nsb;
+                } else {
                     half8_t af[(FP8 || WF == PK_F16) ? 1 : SPB];
                     dequant(w, af);
                     dma_next(sb);
                     sb = nsb;
-                    mma_block(u_tag, w, af);
+                    mma_block(std::integral_constant<int, (e - SE < 0 ? 0 : e - SE)>{}, w, af);
                 }
             });
-            if (cnt & 1) wq[0] = wq[1];   // the next tile's first block is expected in wq[0]
-            kk += cnt;
+            if constexpr (STEPS & 1) wq[0] = wq[1];   // the next tile's first element is expected in wq[0]
+            kk += STEPS;
+        } else if (kk + ept + D <= T) {
+            // the same steady body for a wave that owns fewer blocks than its register slice holds (K split over workgroups:
+            // the 7B down projection gives its waves 5 or 6 of 8)
+            pk_static_for<STEPS>([&](auto e_tag) {
+                constexpr int e = decltype(e_tag)::value;
+                if (e < ept) {   // wave-uniform
+                    uint4_t &w = wq[e & 1];
+                    pk_landed(w);
+                    const unsigned nsb = next_slot(sb);
+                    pk_vmwait<D - 2>();
+                    wq[(e + 1) & 1] = lds_block(nsb);
+                    if constexpr (I4 && e == 0) {
+                        read_scales(sb);
+                        dma_next(sb);
+                        sb = nsb;
+                    } else {
+                        half8_t af[(FP8 || WF == PK_F16) ? 1 : SPB];
+                        dequant(w, af);
+                        dma_next(sb);
+                        sb = nsb;
+                        mma_block(std::integral_constant<int, (e - SE < 0 ? 0 : e - SE)>{}, w, af);
+                    }
+                }
+            });
+            if (ept & 1) wq[0] = wq[1];
+            kk += ept;
         } else {
-            pk_static_for<XBLK>([&](auto u_tag) {
-                constexpr int u = decltype(u_tag)::value;
-                if (u < cnt) {   // wave-uniform
+            pk_static_for<STEPS>([&](auto e_tag) {
+                constexpr int e = decltype(e_tag)::value;
+                if (e < ept) {   // wave-uniform
                     uint4_t w = wq[0];
                     pk_landed(w);
                     half8_t af[(FP8 || WF == PK_F16) ? 1 : SPB];
-                    dequant(w, af);
-                    const int k = kk + u;
+                    if constexpr (I4 && e == 0) read_scales(sb);
+                    else dequant(w, af);
+                    const int k = kk + e;
                     if (k + D < T) dma_next(sb);
                     sb = next_slot(sb);
                     if (k + 1 < T) {
@@ -687,10 +750,10 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
                         else pk_vmwait<0>();
                         wq[0] = lds_block(sb);
                     }
-                    mma_block(u_tag, w, af);
+                    if constexpr (!(I4 && e == 0)) mma_block(std::integral_constant<int, (e - SE < 0 ? 0 : e - SE)>{}, w, af);
                 }
             });
-            kk += cnt;
+            kk += ept;
         }
     };
     int parity = 0;

@@ -26,7 +26,9 @@ size_t pk_packed_bytes(int wf, int N, int K, int swiglu) {
 // int4: packed group-128 scales, one 32-byte record per (tile, block)
 size_t pk_packed_scale_bytes(int wf, int N, int K, int swiglu) {
     if (wf != PK_I4 || K % 128) return 0;
-    return static_cast<size_t>(pk_tiles(N, swiglu)) * (K / 128) * 32;
+    // [tiles][K / 128][16 rows] fp16 + 256 bytes: the kernel fetches a wave's records as one 256-byte DMA, which may run past the
+    // last record of the image
+    return static_cast<size_t>(pk_tiles(N, swiglu)) * (K / 128) * 32 + 256;
 }
 
 int pk_pack(int wf, const void *src, const void *src_scale, void *dst, void *dst_scale, int N, int K, int swiglu, hipStream_t st) {
@@ -97,7 +99,6 @@ int x32_convert(const half_t *src, half_t *dst, int M, int K, int to_x32, hipStr
 }
 
 bool pk_eligible(int wf, int M, int K, int N, int epi) {
-    if (wf == PK_I4) return false;  // group scales need a second stream per tile: not on this kernel yet (packers are ready)
     if (wf == PK_FP8 && M > 16) return false;  // the 32-row fp8 instantiation spills in its quantisation prologue: 16 rows for now
     if (M < 1 || M > 32 || K % pk_kb(wf) || K < 512) return false;  // a wave's activation window is XBLK blocks = 512 k wide
     if (epi == PK_EPI_SWIGLU && (N % 2 || (N / 2) % 4)) return false;
@@ -197,6 +198,7 @@ int pk_linear(int wf, const half_t *x, const void *Wp, const void *scale, half_t
         case PK_F16: pk_launch_f<PK_F16>(mt, kepi, a, p, st); break;
         case PK_I8: pk_launch_f<PK_I8>(mt, kepi, a, p, st); break;
         case PK_FP8: pk_launch_f<PK_FP8>(mt, kepi, a, p, st); break;
+        case PK_I4: pk_launch_f<PK_I4>(mt, kepi, a, p, st); break;   // `scale` = the packed group-scale image of llmie_pack_weight
         default: set_error("linear(packed): unknown format"); return LLMIE_ERR_UNSUPPORTED;
     }
     if (p.KS > 1) {

@@ -110,7 +110,7 @@ def test_pack_weight_bit_exact(llmie, fmt, N, K, swiglu):
         rows = _src_rows(N, swiglu)
         s = np.concatenate([sc.cpu().numpy(), np.zeros((1, K // 128), np.float16)], axis=0)
         exp_s = np.transpose(s[rows], (0, 2, 1))       # [tiles, nblk, 16]
-        got = pscale.cpu().numpy().view(np.float16).reshape(exp_s.shape)
+        got = pscale.cpu().numpy().view(np.float16)[:exp_s.size].reshape(exp_s.shape)   # (+ 256 bytes of padding behind it)
         assert np.array_equal(got, exp_s)
 
 
@@ -133,7 +133,7 @@ SHAPES = [(32, 4096, 1024), (17, 4096, 768), (5, 4096, 512), (16, 4096, 4096), (
           (32, 1024, 144), (32, 4096, 12288), (3, 512, 64)]
 
 
-@pytest.mark.parametrize("fmt", ["int8", "f16"])
+@pytest.mark.parametrize("fmt", ["int8", "f16", "int4"])
 @pytest.mark.parametrize("M,K,N", SHAPES)
 def test_linear_packed_matches_oracle(llmie, fmt, M, K, N):
     rng = np.random.default_rng(42)
@@ -147,7 +147,7 @@ def test_linear_packed_matches_oracle(llmie, fmt, M, K, N):
     assert (err <= 2e-3 + 2e-3 * np.abs(exp)).all(), (err.max(), np.unravel_index(err.argmax(), err.shape))
 
 
-@pytest.mark.parametrize("fmt", ["int8", "f16"])
+@pytest.mark.parametrize("fmt", ["int8", "f16", "int4"])
 @pytest.mark.parametrize("M,K,N", [(32, 4096, 4096), (20, 11008, 4096), (7, 4096, 256)])
 def test_linear_packed_residual_in_place(llmie, fmt, M, K, N):
     """O / down projection form: y = x . W^T + residual with residual aliasing y (self_decoder.cpp:111)"""
@@ -163,7 +163,7 @@ def test_linear_packed_residual_in_place(llmie, fmt, M, K, N):
     assert (err <= 3e-3 + 2e-3 * np.abs(exp)).all(), err.max()
 
 
-@pytest.mark.parametrize("fmt", ["int8", "f16"])
+@pytest.mark.parametrize("fmt", ["int8", "f16", "int4"])
 @pytest.mark.parametrize("M,K,I,pre_bias", [(32, 4096, 11008, False), (13, 4096, 1376, True), (32, 1024, 88, False)])
 def test_linear_packed_norm_swiglu(llmie, fmt, M, K, I, pre_bias):
     """FFN front half in one launch: act = silu(h.Wg^T) * (h.Wu^T), h = rmsnorm(x + pre_bias) * gamma (ffn.cpp:105-122 behind
@@ -185,7 +185,7 @@ def test_linear_packed_norm_swiglu(llmie, fmt, M, K, I, pre_bias):
     assert (err <= 3e-3 + 3e-3 * np.abs(exp)).all(), (err.max(), np.unravel_index(err.argmax(), err.shape))
 
 
-@pytest.mark.parametrize("fmt", ["int8", "f16"])
+@pytest.mark.parametrize("fmt", ["int8", "f16", "int4"])
 def test_linear_packed_norm_plain(llmie, fmt):
     """QKV form: qkv = rmsnorm(x) * gamma . Wqkv^T (self_decoder.cpp:77 + self_attention.cpp:79)"""
     rng = np.random.default_rng(45)
@@ -193,9 +193,9 @@ def test_linear_packed_norm_plain(llmie, fmt):
     wt = _make(fmt, rng, N, K)
     x = _h(rng.standard_normal((M, K)).astype(np.float32) * 3)
     gamma = _h(1 + 0.1 * rng.standard_normal(K).astype(np.float32))
-    packed, _ = llmie.pack_weight(_fmt_code(llmie, fmt), wt["store"], wt["scale"], False)
+    packed, pscale = llmie.pack_weight(_fmt_code(llmie, fmt), wt["store"], wt["scale"], False)
     y = torch.empty((M, N), dtype=F16, device=DEV)
-    llmie.linear_packed(_fmt_code(llmie, fmt), _d(x), packed, wt["scale"], y, N, gamma=_d(gamma), eps=1e-5)
+    llmie.linear_packed(_fmt_code(llmie, fmt), _d(x), packed, pscale if fmt == "int4" else wt["scale"], y, N, gamma=_d(gamma), eps=1e-5)
     hn, _ = orc.rmsnorm(x.copy(), gamma, 1e-5)
     exp = orc.linear(_h(hn), wt["deq"])
     err = np.abs(y.float().cpu().numpy() - exp)
@@ -246,7 +246,7 @@ def test_x32_convert_bit_exact(llmie, M, C):
     assert np.array_equal(back.cpu().numpy(), a)
 
 
-@pytest.mark.parametrize("fmt", ["int8", "f16"])
+@pytest.mark.parametrize("fmt", ["int8", "f16", "int4"])
 @pytest.mark.parametrize("M,K,N,mode", [(32, 4096, 4096, "resid"), (21, 4096, 12288, "norm"), (32, 4096, 22016, "swiglu"),
                                         (32, 11008, 4096, "resid"), (9, 4096, 512, "plain"),
                                         # block-major first pass over 2 / 3 / 4 tiles, then tile-major left-overs; waves that own
@@ -264,10 +264,11 @@ def test_linear_packed_x32_layout_is_bit_identical(llmie, fmt, M, K, N, mode):
     swiglu = mode == "swiglu"
     outN = N // 2 if swiglu else N
     res = _h(rng.standard_normal((M, outN)).astype(np.float32))
-    packed, _ = llmie.pack_weight(code, wt["store"], wt["scale"], swiglu)
+    packed, pscale = llmie.pack_weight(code, wt["store"], wt["scale"], swiglu)
+    wscale = pscale if fmt == "int4" else wt["scale"]
     kw = dict(swiglu=swiglu, gamma=gamma if mode in ("norm", "swiglu") else None, eps=1e-5)
     y_rm = _d(res) if mode == "resid" else torch.zeros((M, outN), dtype=F16, device=DEV)
-    llmie.linear_packed(code, _d(x), packed, wt["scale"], y_rm, N, residual=y_rm if mode == "resid" else None, **kw)
+    llmie.linear_packed(code, _d(x), packed, wscale, y_rm, N, residual=y_rm if mode == "resid" else None, **kw)
     # same call with every activation operand in x32 (the residual in place in the x32 output buffer)
     x_img = torch.empty(32 * K, dtype=F16, device=DEV)
     llmie.x32_convert(_d(x), x_img, M, K, True)
@@ -276,7 +277,7 @@ def test_linear_packed_x32_layout_is_bit_identical(llmie, fmt, M, K, N, mode):
     if mode == "resid":
         llmie.x32_convert(_d(res), y_img, M, outN, True)
         flags |= llmie.X32_RES
-    llmie.linear_packed(code, x_img, packed, wt["scale"], y_img, N, residual=y_img if mode == "resid" else None, M=M, K=K,
+    llmie.linear_packed(code, x_img, packed, wscale, y_img, N, residual=y_img if mode == "resid" else None, M=M, K=K,
                         x32_flags=flags, **kw)
     back = torch.zeros((M, outN), dtype=F16, device=DEV)
     llmie.x32_convert(y_img, back, M, outN, False)
