@@ -683,10 +683,11 @@ static void launch_split(const T *qkv, const T *bias, KT *kc, KT *vc, float *par
                          KvScale ks, PagedKv pg, hipStream_t st) {
     const int bound = step_dev ? max_seq_len : step;
     // chunks per workgroup: a function of the batch geometry ONLY (not of the step: the host-step and the device-step form of
-    // one call must chunk alike), 1 while the grid needs every chunk as its own workgroup, up to 4 for large batches
+    // one call must chunk alike), 1 while the grid needs every chunk as its own workgroup, up to 8 for large batches (batch 32 x 32
+    // heads at ctx 2048: one workgroup per (sequence, head), no partials and no merge launch at all)
     int cpw = 1;
     if constexpr (!std::is_same<KT, T>::value) {   // (e4m3 cache only, see the kernel)
-        while (cpw < 4 && batch * kv_head_num >= 256 * cpw) cpw *= 2;
+        while (cpw < 8 && batch * kv_head_num >= 128 * cpw) cpw *= 2;   // >= 256 workgroups per chunk row are kept
     }
     int CHUNK, splits;
 #define LLMIE_ATTN_LAUNCH(NWV_, GL_)                                                                                   \
