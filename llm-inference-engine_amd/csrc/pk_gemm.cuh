@@ -531,14 +531,17 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
             for (int w = 0; w < NW; ++w) amax = fmaxf(amax, amx[(w * MT + t) * 16 + r]);
             const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
             xscale[t] = sc;   // of token 16 t + r: this lane's B column AND its D column
+            const float rsc = 1.0f / sc;
 #pragma unroll
             for (int u = 0; u < XBLK; ++u)
 #pragma unroll
                 for (int s2 = 0; s2 < SPB; ++s2) {
                     // the e4m3 fragment (8 bytes) replaces the fp16 one in the low half of its register quad
                     const half8_t v = xfrag(xw[u][s2][t]);
-                    xw[u][s2][t][0] = pack4_e4m3(to_f32(v[0]) / sc, to_f32(v[1]) / sc, to_f32(v[2]) / sc, to_f32(v[3]) / sc);
-                    xw[u][s2][t][1] = pack4_e4m3(to_f32(v[4]) / sc, to_f32(v[5]) / sc, to_f32(v[6]) / sc, to_f32(v[7]) / sc);
+                    // (x * (1 / sc), not x / sc: 128 IEEE divisions per lane were 15 us of a 35 us launch at 32 rows; the product
+                    // can differ from the quotient by one ulp before the e4m3 rounding, i.e. flip a code in a rare tie)
+                    xw[u][s2][t][0] = pack4_e4m3(to_f32(v[0]) * rsc, to_f32(v[1]) * rsc, to_f32(v[2]) * rsc, to_f32(v[3]) * rsc);
+                    xw[u][s2][t][1] = pack4_e4m3(to_f32(v[4]) * rsc, to_f32(v[5]) * rsc, to_f32(v[6]) * rsc, to_f32(v[7]) * rsc);
                 }
         }
     }
@@ -568,7 +571,13 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
             float xs = t == 0 ? inv_rms[0] : inv_rms[MT - 1];               // MT <= 2: no runtime-indexed register array
             if constexpr (FP8) xs *= t == 0 ? xscale[0] : xscale[MT - 1];
             if constexpr (EPI == PK_EPI_SLAB) {
-                // unscaled partial sums (the weight-row scale is applied by the reduce launch)
+                // partial sums without the weight-row scale (applied by the reduce launch).  fp8: times THIS slice's activation scale
+                // -- a K-split launch quantises every token's activations per slice (amax over the slice's k range), a finer grid
+                // than the one-scale-per-token of the unsplit launch
+                if constexpr (FP8) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[0][e] *= xs;
+                }
                 if (m < a.M && n0 < a.N)
                     *reinterpret_cast<floatx4 *>(a.slab + (static_cast<size_t>(blockIdx.y) * a.M + m) * a.N + n0) = v[0];
             } else if constexpr (EPI == PK_EPI_SWIGLU) {

@@ -99,12 +99,11 @@ int x32_convert(const half_t *src, half_t *dst, int M, int K, int to_x32, hipStr
 }
 
 bool pk_eligible(int wf, int M, int K, int N, int epi) {
-    if (wf == PK_FP8 && M > 16) return false;  // the 32-row fp8 instantiation spills in its quantisation prologue: 16 rows for now
     if (M < 1 || M > 32 || K % pk_kb(wf) || K < 512) return false;  // a wave's activation window is XBLK blocks = 512 k wide
     if (epi == PK_EPI_SWIGLU && (N % 2 || (N / 2) % 4)) return false;
     if (epi != PK_EPI_SWIGLU && N % 4) return false;
     PkPlan p;
-    return pk_plan(wf, K, 1, epi != PK_EPI_SWIGLU && wf != PK_FP8, &p);
+    return pk_plan(wf, K, 1, epi != PK_EPI_SWIGLU, &p);
 }
 
 // K slices this shape will use (1 = epilogue in registers, no slabs); 0 if not eligible
@@ -112,7 +111,7 @@ int pk_slices(int wf, int M, int K, int N, int epi, bool norm) {
     if (!pk_eligible(wf, M, K, N, epi)) return 0;
     PkPlan p;
     const int units = epi == PK_EPI_SWIGLU ? pk_tiles(N, 1) / 2 : pk_tiles(N, 0);
-    if (!pk_plan(wf, K, units, epi != PK_EPI_SWIGLU && !norm && wf != PK_FP8, &p)) return 0;
+    if (!pk_plan(wf, K, units, epi != PK_EPI_SWIGLU && !norm, &p)) return 0;
     return p.KS;
 }
 size_t pk_slab_floats(int wf, int M, int K, int N) {
@@ -165,7 +164,7 @@ int pk_linear(int wf, const half_t *x, const void *Wp, const void *scale, half_t
     }
     const int units = epi == PK_EPI_SWIGLU ? pk_tiles(N, 1) / 2 : pk_tiles(N, 0);
     PkPlan p;
-    if (!pk_plan(wf, K, units, epi != PK_EPI_SWIGLU && !gamma && wf != PK_FP8 /* per-token scales: no K split */, &p)) {
+    if (!pk_plan(wf, K, units, epi != PK_EPI_SWIGLU && !gamma, &p)) {
         set_error("linear(packed): K=%d does not fit the register-resident activation slice%s", K, gamma ? " (fused norm: no K split)" : "");
         return LLMIE_ERR_UNSUPPORTED;
     }
@@ -186,10 +185,6 @@ int pk_linear(int wf, const half_t *x, const void *Wp, const void *scale, half_t
             set_error("linear(packed): split-K workspace too small (%zu < %zu floats)", slab_ws_floats, static_cast<size_t>(p.KS) * M * N);
             return LLMIE_ERR_WORKSPACE;
         }
-        if (wf == PK_FP8) {
-            set_error("linear(packed fp8): K=%d needs a K split, which per-token activation scales do not allow", K);
-            return LLMIE_ERR_UNSUPPORTED;
-        }
         a.slab = slab_ws;
         kepi = PK_EPI_SLAB;
     }
@@ -204,8 +199,8 @@ int pk_linear(int wf, const half_t *x, const void *Wp, const void *scale, half_t
     if (p.KS > 1) {
         const size_t total4 = static_cast<size_t>(M) * N / 4;
         const int grid = static_cast<int>((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
-        pk_slab_reduce_kernel<<<grid, 256, 0, st>>>(slab_ws, p.KS, M, N, wf == PK_I8 ? static_cast<const half_t *>(scale) : nullptr, nullptr, nullptr,
-                                                    residual, y, res_x32, y_x32);
+        pk_slab_reduce_kernel<<<grid, 256, 0, st>>>(slab_ws, p.KS, M, N, wf == PK_I8 ? static_cast<const half_t *>(scale) : nullptr,
+                                                    wf == PK_FP8 ? static_cast<const float *>(scale) : nullptr, nullptr, residual, y, res_x32, y_x32);
     }
     return launch_status("linear(packed)");
 }
