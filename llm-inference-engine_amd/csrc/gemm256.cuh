@@ -22,6 +22,95 @@ namespace llmie {
 // rate -- and the epilogue applies xscale[m] * wscale[n].
 typedef int intx8 __attribute__((ext_vector_type(8)));
 
+// Epilogue shared by the 256-row kernels (this file and gemm8p.cuh): acc[i][j] of wave (wr, wc): lane (r, q) holds
+// C[m0 + wr*128 + i*16 + r][n0 + wcol + j*16 + 4q + e]; SwiGLU: acc[i][jj] = gate, acc[i][2 + jj] = up of column n0 + wcol + 16 jj + 4q + e.
+template <bool FP8, bool HAS_EPI, int WN, bool SWIGLU>
+__device__ __forceinline__ void g256_store(floatx4 (&acc)[8][WN], half_t *C, int M, int N, size_t ldc, int m0, int n0, int wr, int wcol,
+                                           int r, int q, const half_t *__restrict__ bias, const half_t *residual,
+                                           const float *__restrict__ xscale, const float *__restrict__ wscale) {
+    const int half_n = N >> 1;
+    if constexpr (SWIGLU) {
+        // acc[i][jj] = gate, acc[i][2 + jj] = up of C columns n0 + wcol + 16 jj + 4q + e
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + wr * 128 + i * 16 + r;
+            if (m >= M) continue;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int n = n0 + wcol + jj * 16 + 4 * q;
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float gt = acc[i][jj][e], up = acc[i][2 + jj][e];
+                    if constexpr (FP8) {
+                        const float xsm = xscale[m];
+                        gt *= wscale[min(n + e, half_n - 1)] * xsm;
+                        up *= wscale[half_n + min(n + e, half_n - 1)] * xsm;
+                    }
+                    // the unfused sequence rounds gate and up to fp16 before SiluAndMul: keep the same roundings
+                    gt = to_f32(from_f32<half_t>(gt));
+                    up = to_f32(from_f32<half_t>(up));
+                    o[e] = (gt / (1.0f + expf(-gt))) * up;
+                }
+                if (n + 3 < half_n && (half_n & 3) == 0) {
+                    const half4_t o4 = {from_f32<half_t>(o[0]), from_f32<half_t>(o[1]), from_f32<half_t>(o[2]), from_f32<half_t>(o[3])};
+                    *reinterpret_cast<half4_t *>(C + static_cast<size_t>(m) * half_n + n) = o4;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < half_n) C[static_cast<size_t>(m) * half_n + n + e] = from_f32<half_t>(o[e]);
+                }
+            }
+        }
+        return;
+    }
+    // acc[i][j]: lane holds C[m0 + wr*128 + i*16 + r][n0 + wcol + j*16 + 4q + e]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + r;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int n = n0 + wcol + j * 16 + 4 * q;
+            if (n + 3 < N && (N & 3) == 0 && (ldc & 3) == 0) {
+                floatx4 v = acc[i][j];
+                if constexpr (FP8) {
+                    const floatx4 ws = *reinterpret_cast<const floatx4 *>(wscale + n);
+                    const float xsm = xscale[m];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= ws[e] * xsm;
+                }
+                if (HAS_EPI) {
+                    if (bias) {
+                        const half4_t b4 = *reinterpret_cast<const half4_t *>(bias + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += to_f32(b4[e]);
+                    }
+                    if (residual) {
+                        const half4_t r4 = *reinterpret_cast<const half4_t *>(residual + static_cast<size_t>(m) * ldc + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += to_f32(r4[e]);
+                    }
+                }
+                const half4_t o = {from_f32<half_t>(v[0]), from_f32<half_t>(v[1]), from_f32<half_t>(v[2]), from_f32<half_t>(v[3])};
+                *reinterpret_cast<half4_t *>(C + static_cast<size_t>(m) * ldc + n) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < N) {
+                        float v = acc[i][j][e];
+                        if constexpr (FP8) v *= wscale[n + e] * xscale[m];
+                        if (HAS_EPI) {
+                            if (bias) v += to_f32(bias[n + e]);
+                            if (residual) v += to_f32(residual[static_cast<size_t>(m) * ldc + n + e]);
+                        }
+                        C[static_cast<size_t>(m) * ldc + n + e] = from_f32<half_t>(v);
+                    }
+            }
+        }
+    }
+}
+
 // WN = MFMA column tiles per wave: 4 -> 256 x 256 workgroup tile, 2 -> 256 x 128 (one W half per stage, 96 KiB of LDS) for
 // projections whose 256-wide grid would leave CUs idle (N = 4096 at 2048 tokens: 128 vs 256 workgroups).
 // SWIGLU (WN = 4, W = fused gate_up [2I, K]): the workgroup's 256 weight rows are 128 gate rows n0 .. and the 128 up rows
@@ -168,86 +257,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const void *__restrict__ X
         __syncthreads();  // every wave done with this stage; the next stage's DMA has landed (the barrier drains vmcnt)
     }
 
-    if constexpr (SWIGLU) {
-        // acc[i][jj] = gate, acc[i][2 + jj] = up of C columns n0 + wcol + 16 jj + 4q + e
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m = m0 + wr * 128 + i * 16 + r;
-            if (m >= M) continue;
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int n = n0 + wcol + jj * 16 + 4 * q;
-                float o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float gt = acc[i][jj][e], up = acc[i][2 + jj][e];
-                    if constexpr (FP8) {
-                        const float xsm = xscale[m];
-                        gt *= wscale[min(n + e, half_n - 1)] * xsm;
-                        up *= wscale[half_n + min(n + e, half_n - 1)] * xsm;
-                    }
-                    // the unfused sequence rounds gate and up to fp16 before SiluAndMul: keep the same roundings
-                    gt = to_f32(from_f32<half_t>(gt));
-                    up = to_f32(from_f32<half_t>(up));
-                    o[e] = (gt / (1.0f + expf(-gt))) * up;
-                }
-                if (n + 3 < half_n && (half_n & 3) == 0) {
-                    const half4_t o4 = {from_f32<half_t>(o[0]), from_f32<half_t>(o[1]), from_f32<half_t>(o[2]), from_f32<half_t>(o[3])};
-                    *reinterpret_cast<half4_t *>(C + static_cast<size_t>(m) * half_n + n) = o4;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < half_n) C[static_cast<size_t>(m) * half_n + n + e] = from_f32<half_t>(o[e]);
-                }
-            }
-        }
-        return;
-    }
-    // acc[i][j]: lane holds C[m0 + wr*128 + i*16 + r][n0 + wcol + j*16 + 4q + e]
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wr * 128 + i * 16 + r;
-        if (m >= M) continue;
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int n = n0 + wcol + j * 16 + 4 * q;
-            if (n + 3 < N && (N & 3) == 0 && (ldc & 3) == 0) {
-                floatx4 v = acc[i][j];
-                if constexpr (FP8) {
-                    const floatx4 ws = *reinterpret_cast<const floatx4 *>(wscale + n);
-                    const float xsm = xscale[m];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= ws[e] * xsm;
-                }
-                if (HAS_EPI) {
-                    if (bias) {
-                        const half4_t b4 = *reinterpret_cast<const half4_t *>(bias + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += to_f32(b4[e]);
-                    }
-                    if (residual) {
-                        const half4_t r4 = *reinterpret_cast<const half4_t *>(residual + static_cast<size_t>(m) * ldc + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += to_f32(r4[e]);
-                    }
-                }
-                const half4_t o = {from_f32<half_t>(v[0]), from_f32<half_t>(v[1]), from_f32<half_t>(v[2]), from_f32<half_t>(v[3])};
-                *reinterpret_cast<half4_t *>(C + static_cast<size_t>(m) * ldc + n) = o;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n + e < N) {
-                        float v = acc[i][j][e];
-                        if constexpr (FP8) v *= wscale[n + e] * xscale[m];
-                        if (HAS_EPI) {
-                            if (bias) v += to_f32(bias[n + e]);
-                            if (residual) v += to_f32(residual[static_cast<size_t>(m) * ldc + n + e]);
-                        }
-                        C[static_cast<size_t>(m) * ldc + n + e] = from_f32<half_t>(v);
-                    }
-            }
-        }
-    }
+    g256_store<FP8, HAS_EPI, WN, SWIGLU>(acc, C, M, N, ldc, m0, n0, wr, wcol, r, q, bias, residual, xscale, wscale);
 }
 
 }  // namespace llmie

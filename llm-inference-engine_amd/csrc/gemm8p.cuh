@@ -1,0 +1,410 @@
+// 256 x 256 x 64 MFMA GEMM, eight-phase ping-pong schedule (gfx950):  C[M,N] = X[M,K] . W[N,K]^T (+bias)(+residual) or the fused
+// SwiGLU form -- the same operation, operands, tile geometry, LDS image and epilogue as gemm256_kernel<.., WN = 4> (gemm256.cuh: the
+// linear of launchLinearGemm, linear.cu:10-87, at prefill sizes), with a different main loop.
+//
+// gemm256_kernel runs its eight waves in lock step: every wave reads its 12 fragments of a k-tile, multiplies, and all meet at one
+// barrier per k-tile that also drains the LDS-DMA of the next tile (vmcnt(0)); its MFMA pipes are busy 51 % of the time
+// (profiles/r02_gemm256_pmc.csv).  Here
+//   * the two wave rows (wr = 0 / 1: one wave of each on every SIMD) run half a phase apart: while one group issues its 16 MFMAs of
+//     a phase (one 64 x 32 quadrant of the wave's 128 x 64 tile over the 64-deep k-tile) the other reads the fragments of its next
+//     quadrant and issues its share of the LDS-DMA, and the two swap at every barrier -- the MFMA pipe of a SIMD always has a
+//     wave to serve and the LDS reads of one group hide under the arithmetic of the other;
+//   * a k-tile is four phases (quadrants (0,0) (0,1) (1,1) (1,0)); a phase reads ONE operand piece -- A rows 0-63, B columns 32-63,
+//     A rows 64-127, B columns 0-31 of the NEXT k-tile (8 / 4 / 8 / 4 ds_read_b128 per wave) -- so only the piece that changes
+//     between two consecutive quadrants is fetched, and the B piece of the first quadrant is already in registers when a tile starts;
+//   * the LDS-DMA runs in the same four pieces ("groups" of 16 KiB = 2 wave instructions per wave, filled by all eight waves), one
+//     group per phase, five groups (80 KiB) in flight: phase p reads group p + 1, waits until group p + 2 has landed (a counted
+//     s_waitcnt vmcnt(10), never 0 in the steady state) and issues group p + 7 into the slot that group p - 1 occupied;
+//   * the DMA is issued from inline asm and counted by hand (hipcc orders LDS accesses of its own behind a pending builtin DMA with
+//     vmcnt(0)); raw s_barrier, no fence.
+// Ordering rules this schedule is built on (MI355X guide, "Read a staged buffer one phase AFTER the wait that retires it"): with
+// the groups staggered by one barrier, a group waited for in phase p (before the phase's first barrier) is visible to every wave's
+// reads from phase p + 1; a slot may be refilled two phases after its last read (the reads are retired by the lgkmcnt(0) behind the
+// reading phase's first barrier).  Both hold with equality here: read p + 1 / retire p + 2 / refill (p - 1)'s slot, whose last
+// read was phase p - 2.
+#pragma once
+#include "gemm256.cuh"
+
+namespace llmie {
+
+__device__ __forceinline__ void g8_dma16(const unsigned voff, const void *sbase, const unsigned lds_dst) {
+    // 1 KiB per wave: 16 bytes per lane from sbase + voff -> LDS lds_dst + 16 lane (M0 written in the statement that uses it)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+// one operand fragment of a k-tile: fp16 -> the two 32-deep k-steps, e4m3 -> one 128-deep step (8 registers the MFMA takes whole)
+template <bool FP8> struct G8Frag;
+template <> struct G8Frag<false> { half8_t k[2]; };
+template <> struct G8Frag<true> { intx8 v; };
+template <bool FP8> __device__ __forceinline__ void g8_read(G8Frag<FP8> &f, const unsigned char *p, unsigned sw0, unsigned sw1) {
+    const uint4_t lo = *reinterpret_cast<const uint4_t *>(p + sw0), hi = *reinterpret_cast<const uint4_t *>(p + sw1);
+    if constexpr (FP8) {
+        f.v = intx8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+    } else {
+        f.k[0] = __builtin_bit_cast(half8_t, lo);
+        f.k[1] = __builtin_bit_cast(half8_t, hi);
+    }
+}
+template <bool FP8> __device__ __forceinline__ void g8_mma(floatx4 &acc, const G8Frag<FP8> &w, const G8Frag<FP8> &x, int k) {
+    if constexpr (FP8) acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w.v, x.v, acc, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    else acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.k[k], x.k[k], acc, 0, 0, 0);
+}
+// Placement pins (no instructions): the MFMAs of a phase read fragments that pass through g8_pin AFTER the phase's lgkmcnt(0) and
+// write accumulators that pass through g8_pin BEFORE the closing barrier, so no IR pass can sink them out of the phase or hoist
+// them into the read segment (sched_barrier only binds the machine scheduler; without the pins the e4m3 form had its MFMAs sunk
+// several phases down and spilled the fragments they kept alive).
+__device__ __forceinline__ void g8_pin(floatx4 &a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void g8_pin(G8Frag<false> &f) { asm volatile("" : "+v"(f.k[0]), "+v"(f.k[1])); }
+__device__ __forceinline__ void g8_pin(G8Frag<true> &f) { asm volatile("" : "+v"(f.v)); }
+// wait until all but the newest `groups` DMA groups (2 wave instructions each) of this wave have landed
+__device__ __forceinline__ void g8_wait_groups(int groups) {
+    if (groups >= 5) {   // the steady state: one compare
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        return;
+    }
+    if (groups == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (groups == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (groups == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (groups == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <bool FP8, bool HAS_EPI, bool SWIGLU = false>
+__global__ __launch_bounds__(512) void gemm8p_kernel(const void *__restrict__ Xv, const void *__restrict__ Wv, half_t *C, int M, int N,
+                                                     int K, const half_t *__restrict__ bias, const half_t *residual, int tiles_n,
+                                                     const float *__restrict__ xscale, const float *__restrict__ wscale,
+                                                     int ldc_arg = 0, int group_m = 0) {
+    static_assert(!SWIGLU || !HAS_EPI, "SwiGLU form: no bias / residual");
+    const size_t ldc = ldc_arg ? ldc_arg : N;
+    constexpr int ES = FP8 ? 1 : 2, BK = 128 / ES;
+    constexpr int BN = SWIGLU ? 128 : 256;
+    const int half_n = N >> 1;
+    constexpr unsigned HALF_BYTES = 128 * 128, STAGE_BYTES = 4 * HALF_BYTES;   // stage: A half 0 | A half 1 | B half 0 | B half 1
+    const unsigned char *X = static_cast<const unsigned char *>(Xv), *W = static_cast<const unsigned char *>(Wv);
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];  // [2 stages][4 halves][128 rows x 128 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int r = lane & 15, q = lane >> 4;
+    int tile_m, tile_n;
+    if (group_m > 0) {   // XCD-aware tile order, as in gemm256_kernel
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int qd = nwg >> 3, rem = nwg & 7;
+        const int L = xcd * qd + min(xcd, rem) + idx;
+        const int tm = (M + 255) / 256, per_group = group_m * tiles_n;
+        const int grp = L / per_group, in = L - grp * per_group;
+        const int first_m = grp * group_m, gsz = min(tm - first_m, group_m);
+        tile_m = first_m + in % gsz;
+        tile_n = in / gsz;
+    } else {
+        tile_m = blockIdx.x / tiles_n;
+        tile_n = blockIdx.x - tile_m * tiles_n;
+    }
+    const int m0 = tile_m * 256, n0 = tile_n * BN;
+
+    // ---- DMA plan.  Group kinds: 0 = A rows 0-63 of both halves, 1 = B first column piece, 2 = B second column piece,
+    //      3 = A rows 64-127.  A group = 16 pieces of 8 rows x 128 B; this wave moves pieces pi = i*8 + wave, i = 0, 1.
+    //      lane -> row lane/8 of the piece, LDS slot lane%8 <- source chunk slot ^ (row & 7)  (swizzle on the source side)
+    const size_t row_bytes = static_cast<size_t>(K) * ES;
+    const unsigned char *xbase = X + static_cast<size_t>(m0) * row_bytes;   // wave-uniform bases; the per-lane part is 32-bit
+    const unsigned char *wbase = W + static_cast<size_t>(n0) * row_bytes;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    const unsigned lds_addr = static_cast<unsigned>(reinterpret_cast<size_t>((lptr_t)lds));   // LDS byte address of the image
+    unsigned voff[4][2], ldst[4][2];
+#pragma unroll
+    for (int kind = 0; kind < 4; ++kind)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pi = i * 8 + wave;
+            int half, row0;   // LDS half (0..3) and first row of the piece inside it
+            if (kind == 0 || kind == 3) {
+                half = pi >> 3;
+                row0 = (pi & 7) * 8 + (kind == 3 ? 64 : 0);
+            } else if (SWIGLU) {
+                half = 2 + (kind - 1);   // gate half / up half, all 128 rows
+                row0 = pi * 8;
+            } else {
+                half = 2 + (pi >> 3);
+                row0 = ((pi >> 2) & 1) * 64 + (kind - 1) * 32 + (pi & 3) * 8;
+            }
+            const int row = row0 + (lane >> 3), chunk = (lane & 7) ^ (row & 7);
+            long grow;   // row relative to the tile base, clamped to the matrix (edge rows are never stored)
+            if (half < 2) grow = min(m0 + half * 128 + row, M - 1) - m0;
+            else if (SWIGLU) grow = static_cast<long>(half - 2) * half_n + min(n0 + row, half_n - 1) - n0;
+            else grow = min(n0 + (half - 2) * 128 + row, N - 1) - n0;
+            voff[kind][i] = static_cast<unsigned>(grow * static_cast<long>(row_bytes) + chunk * 16);
+            ldst[kind][i] = __builtin_amdgcn_readfirstlane(lds_addr + half * HALF_BYTES + row0 * 128);
+        }
+    auto issue = [&](auto kind_, int kt, unsigned stage) {
+        constexpr int kind = decltype(kind_)::value;
+        const unsigned char *base = ((kind == 0 || kind == 3) ? xbase : wbase) + static_cast<size_t>(kt) * 128;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) g8_dma16(voff[kind][i], base, ldst[kind][i] + stage * STAGE_BYTES);
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    using K3 = std::integral_constant<int, 3>;
+
+    floatx4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- fragment reads: 16-byte piece k (0, 1) of row `row`: fp16 -> chunk k*4 + q (k-step k), e4m3 -> chunk 2q + k (one 128-deep step)
+    const int wcol = SWIGLU ? wc * 32 : wc * 64;
+    const unsigned sw0 = static_cast<unsigned>(((FP8 ? 2 * q : q) ^ (r & 7)) << 4), sw1 = static_cast<unsigned>(((FP8 ? 2 * q + 1 : 4 + q) ^ (r & 7)) << 4);
+    const unsigned a_lane = wr * HALF_BYTES + r * 128;   // + stage, + (ih*64 + i*16) * 128, + sw
+    // B piece jh, fragment jj: plain -> half 2 + (wc >> 1), row (wc & 1)*64 + jh*32 + jj*16 + r;  SwiGLU -> half 2 + jh, row wc*32 + jj*16 + r
+    const unsigned b_lane = SWIGLU ? 2 * HALF_BYTES + (wc * 32 + r) * 128 : (2 + (wc >> 1)) * HALF_BYTES + ((wc & 1) * 64 + r) * 128;
+    constexpr unsigned B_PIECE = SWIGLU ? HALF_BYTES : 32 * 128;
+    G8Frag<FP8> fa[4], fb0[2][2], fb1[2];   // A piece (4 row tiles), B first piece of even / odd k-tiles, B second piece
+    auto read_a = [&](unsigned stage, int ih) {
+        const unsigned char *p = lds + stage * STAGE_BYTES + a_lane + ih * 64 * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g8_read<FP8>(fa[i], p + i * 2048, sw0, sw1);
+    };
+    auto read_b = [&](unsigned stage, int jh, G8Frag<FP8> (&f)[2]) {
+        const unsigned char *p = lds + stage * STAGE_BYTES + b_lane + jh * B_PIECE;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) g8_read<FP8>(f[jj], p + jj * 2048, sw0, sw1);
+    };
+    auto quadrant = [&](auto ih_, auto jh_, G8Frag<FP8> (&f)[2]) {
+        constexpr int ih = decltype(ih_)::value, jh = decltype(jh_)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g8_pin(fa[i]);
+        g8_pin(f[0]); g8_pin(f[1]);
+#pragma unroll
+        for (int k = 0; k < (FP8 ? 1 : 2); ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) g8_mma<FP8>(acc[ih * 4 + i][jh * 2 + jj], f[jj], fa[i], k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) g8_pin(acc[ih * 4 + i][jh * 2 + jj]);
+    };
+
+    const int KT = K / BK, G = 4 * KT;   // k-tiles, DMA groups (group g: k-tile g / 4, kind {1, 0, 2, 3}[g % 4])
+    // ---- prologue: groups 0..6 (k-tile 0 whole, k-tile 1 without its last piece)
+    issue(K1{}, 0, 0); issue(K0{}, 0, 0); issue(K2{}, 0, 0); issue(K3{}, 0, 0);
+    if (KT > 1) { issue(K1{}, 1, 1); issue(K0{}, 1, 1); issue(K2{}, 1, 1); }
+    g8_wait_groups(min(7, G) - 2);   // groups 0 and 1 landed
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_b(0, 0, fb0[0]);
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // the second wave row runs one barrier behind from here on
+    asm volatile("" ::: "memory");
+
+    // phase S (0..7) of the two-k-tile loop body: k-tile u (parity S / 4), quadrant S % 4
+    auto phase = [&](auto S_, int u) {
+        constexpr int S = decltype(S_)::value, s = S & 3;
+        constexpr unsigned par = S >> 2;
+        // reads of this phase's new piece (group 4u + s + 1)
+        if constexpr (s == 0) read_a(par, 0);
+        else if constexpr (s == 1) read_b(par, 1, fb1);
+        else if constexpr (s == 2) read_a(par, 1);
+        else if (u + 1 < KT) read_b(par ^ 1, 0, fb0[par ^ 1]);
+        // DMA group 4u + s + 7
+        if constexpr (s == 0) { if (u + 1 < KT) issue(K3{}, u + 1, par ^ 1); }
+        else if constexpr (s == 1) { if (u + 2 < KT) issue(K1{}, u + 2, par); }
+        else if constexpr (s == 2) { if (u + 2 < KT) issue(K0{}, u + 2, par); }
+        else { if (u + 2 < KT) issue(K2{}, u + 2, par); }
+        g8_wait_groups(G - (4 * u + s) - 3);   // group 4u + s + 2 landed: the next phase reads it
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        if constexpr (s == 0) quadrant(K0{}, K0{}, fb0[par]);
+        else if constexpr (s == 1) quadrant(K0{}, K1{}, fb1);
+        else if constexpr (s == 2) quadrant(K1{}, K1{}, fb1);
+        else quadrant(K1{}, K0{}, fb0[par]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    int u = 0;
+    for (; u + 1 < KT; u += 2) {
+        phase(std::integral_constant<int, 0>{}, u); phase(std::integral_constant<int, 1>{}, u);
+        phase(std::integral_constant<int, 2>{}, u); phase(std::integral_constant<int, 3>{}, u);
+        phase(std::integral_constant<int, 4>{}, u + 1); phase(std::integral_constant<int, 5>{}, u + 1);
+        phase(std::integral_constant<int, 6>{}, u + 1); phase(std::integral_constant<int, 7>{}, u + 1);
+    }
+    if (u < KT) {   // odd number of k-tiles: the last one has even parity
+        phase(std::integral_constant<int, 0>{}, u); phase(std::integral_constant<int, 1>{}, u);
+        phase(std::integral_constant<int, 2>{}, u); phase(std::integral_constant<int, 3>{}, u);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with the second row's last barrier
+
+    g256_store<FP8, HAS_EPI, 4, SWIGLU>(acc, C, M, N, ldc, m0, n0, wr, wcol, r, q, bias, residual, xscale, wscale);
+}
+
+// ---- 256 x 128 tile in the same schedule, for projections whose 256-wide grid would leave CUs idle (N = 4096 at 2048 tokens).
+// Wave tile 128 x 32: a k-tile is TWO phases (A rows 0-63, A rows 64-127, each against the tile's 32 columns), and three DMA
+// groups: B (128 weight rows), A0 (rows 0-63 of both 128-row halves), A1 (rows 64-127), 16 KiB each, in a ring of nine 16-KiB
+// slots (group g -> slot g % 9; three k-tiles = six phases per loop body keep every LDS address static).
+//   phase 2u:     reads A0(u) = group 3u+1;              issues A0(u+2) = group 3u+7;            waits until group 3u+3 has landed
+//   phase 2u + 1: reads A1(u), B(u+1) = groups 3u+2, 3u+3; issues A1(u+2), B(u+3) = groups 3u+8, 3u+9; waits until group 3u+4 has landed
+// Slot reuse: group g + 9 is issued exactly two phases after the last read of group g (A0(u-1): read 2u-2, refilled 2u;
+// A1(u-1): 2u-1 -> 2u+1; B(u): 2u-1 -> 2u+1); 4-5 groups (64-80 KiB) in flight.
+__device__ __forceinline__ void g8_wait_instrs(int n) {   // n = DMA wave instructions that may stay in flight (even, 0..10)
+    if (n >= 10) { asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); return; }
+    if (n >= 8) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); return; }
+    if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <bool FP8, bool HAS_EPI>
+__global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict__ Xv, const void *__restrict__ Wv, half_t *C, int M, int N,
+                                                          int K, const half_t *__restrict__ bias, const half_t *residual, int tiles_n,
+                                                          const float *__restrict__ xscale, const float *__restrict__ wscale,
+                                                          int ldc_arg = 0, int group_m = 0) {
+    const size_t ldc = ldc_arg ? ldc_arg : N;
+    constexpr int ES = FP8 ? 1 : 2, BK = 128 / ES;
+    constexpr unsigned SLOT_BYTES = 128 * 128;
+    const unsigned char *X = static_cast<const unsigned char *>(Xv), *W = static_cast<const unsigned char *>(Wv);
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];  // [9 slots][128 rows x 128 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int r = lane & 15, q = lane >> 4;
+    int tile_m, tile_n;
+    if (group_m > 0) {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int qd = nwg >> 3, rem = nwg & 7;
+        const int L = xcd * qd + min(xcd, rem) + idx;
+        const int tm = (M + 255) / 256, per_group = group_m * tiles_n;
+        const int grp = L / per_group, in = L - grp * per_group;
+        const int first_m = grp * group_m, gsz = min(tm - first_m, group_m);
+        tile_m = first_m + in % gsz;
+        tile_n = in / gsz;
+    } else {
+        tile_m = blockIdx.x / tiles_n;
+        tile_n = blockIdx.x - tile_m * tiles_n;
+    }
+    const int m0 = tile_m * 256, n0 = tile_n * 128;
+
+    // DMA plan: kind 0 = B, 1 = A0, 2 = A1 (the group order inside a k-tile); this wave moves pieces pi = i*8 + wave (8 slot rows each)
+    const size_t row_bytes = static_cast<size_t>(K) * ES;
+    const unsigned char *xbase = X + static_cast<size_t>(m0) * row_bytes, *wbase = W + static_cast<size_t>(n0) * row_bytes;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    const unsigned lds_addr = static_cast<unsigned>(reinterpret_cast<size_t>((lptr_t)lds));
+    unsigned voff[3][2], ldst[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pi = i * 8 + wave, row = pi * 8 + (lane >> 3), chunk = (lane & 7) ^ (row & 7);   // slot row of this lane
+        ldst[i] = __builtin_amdgcn_readfirstlane(lds_addr + pi * 1024);
+        voff[0][i] = static_cast<unsigned>(static_cast<long>(min(n0 + row, N - 1) - n0) * static_cast<long>(row_bytes) + chunk * 16);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {   // slot rows 0-63 -> A half 0, 64-127 -> A half 1; rows (row % 64) + 64 a of the half
+            const int arow = (row >> 6) * 128 + (row & 63) + 64 * a;
+            voff[1 + a][i] = static_cast<unsigned>(static_cast<long>(min(m0 + arow, M - 1) - m0) * static_cast<long>(row_bytes) + chunk * 16);
+        }
+    }
+    auto issue = [&](auto kind_, int kt, unsigned slot) {
+        constexpr int kind = decltype(kind_)::value;
+        const unsigned char *base = (kind == 0 ? wbase : xbase) + static_cast<size_t>(kt) * 128;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) g8_dma16(voff[kind][i], base, ldst[i] + slot * SLOT_BYTES);
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+
+    floatx4 acc[8][2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int wcol = wc * 32;
+    const unsigned sw0 = static_cast<unsigned>(((FP8 ? 2 * q : q) ^ (r & 7)) << 4), sw1 = static_cast<unsigned>(((FP8 ? 2 * q + 1 : 4 + q) ^ (r & 7)) << 4);
+    const unsigned a_lane = (wr * 64 + r) * 128, b_lane = (wc * 32 + r) * 128;
+    G8Frag<FP8> fa[4], fb[3][2];   // A piece; B fragments of k-tiles u % 3 = 0, 1, 2
+    auto read_a = [&](unsigned slot) {
+        const unsigned char *p = lds + slot * SLOT_BYTES + a_lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g8_read<FP8>(fa[i], p + i * 2048, sw0, sw1);
+    };
+    auto read_b = [&](unsigned slot, G8Frag<FP8> (&f)[2]) {
+        const unsigned char *p = lds + slot * SLOT_BYTES + b_lane;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) g8_read<FP8>(f[jj], p + jj * 2048, sw0, sw1);
+    };
+    auto half_tile = [&](auto ih_, G8Frag<FP8> (&f)[2]) {
+        constexpr int ih = decltype(ih_)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g8_pin(fa[i]);
+        g8_pin(f[0]); g8_pin(f[1]);
+#pragma unroll
+        for (int k = 0; k < (FP8 ? 1 : 2); ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) g8_mma<FP8>(acc[ih * 4 + i][jj], f[jj], fa[i], k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) g8_pin(acc[ih * 4 + i][jj]);
+    };
+
+    const int KT = K / BK, G = 3 * KT;   // DMA groups: group g = k-tile g / 3, kind g % 3, slot g % 9
+    // prologue: groups 0..6
+    issue(K0{}, 0, 0); issue(K1{}, 0, 1); issue(K2{}, 0, 2);
+    if (KT > 1) { issue(K0{}, 1, 3); issue(K1{}, 1, 4); issue(K2{}, 1, 5); }
+    if (KT > 2) issue(K0{}, 2, 6);
+    g8_wait_instrs(2 * (min(7, G) - 2));   // groups 0 and 1 landed
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_b(0, fb[0]);
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    // phase S (0..5) of the three-k-tile loop body: k-tile u with u % 3 = S / 2
+    auto phase = [&](auto S_, int u) {
+        constexpr int S = decltype(S_)::value, s = S & 1;
+        constexpr unsigned c = S >> 1, c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+        if constexpr (s == 0) {
+            read_a(3 * c + 1);
+            if (u + 2 < KT) issue(K1{}, u + 2, 3 * c2 + 1);
+            g8_wait_instrs(2 * min(4, G - 3 * u - 4));
+        } else {
+            read_a(3 * c + 2);
+            if (u + 1 < KT) read_b(3 * c1, fb[c1]);
+            if (u + 2 < KT) issue(K2{}, u + 2, 3 * c2 + 2);
+            if (u + 3 < KT) issue(K0{}, u + 3, 3 * c);
+            g8_wait_instrs(2 * min(5, G - 3 * u - 5));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        if constexpr (s == 0) half_tile(K0{}, fb[c]);
+        else half_tile(K1{}, fb[c]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    int u = 0;
+    for (; u + 2 < KT; u += 3) {
+        phase(std::integral_constant<int, 0>{}, u); phase(std::integral_constant<int, 1>{}, u);
+        phase(std::integral_constant<int, 2>{}, u + 1); phase(std::integral_constant<int, 3>{}, u + 1);
+        phase(std::integral_constant<int, 4>{}, u + 2); phase(std::integral_constant<int, 5>{}, u + 2);
+    }
+    if (u < KT) { phase(std::integral_constant<int, 0>{}, u); phase(std::integral_constant<int, 1>{}, u); }
+    if (u + 1 < KT) { phase(std::integral_constant<int, 2>{}, u + 1); phase(std::integral_constant<int, 3>{}, u + 1); }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+
+    g256_store<FP8, HAS_EPI, 2, false>(acc, C, M, N, ldc, m0, n0, wr, wcol, r, q, bias, residual, xscale, wscale);
+}
+
+}  // namespace llmie

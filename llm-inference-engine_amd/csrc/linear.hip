@@ -1,6 +1,7 @@
 // llmie_linear / llmie_batched_gemm: shape dispatch over the kernels in gemm_kernels.cuh.
 #include "gemm_kernels.cuh"
 #include "gemm256.cuh"
+#include "gemm8p.cuh"
 #include "gemm_mid.cuh"
 #include "llmie_internal.h"
 
@@ -508,6 +509,11 @@ static int gemm256_wn(int M, int N) {
 }
 bool gemm256_fills(int M, int N) { return gemm256_wn(M, N) != 0; }
 
+// eight-phase form of the 256 x 256 tile (gemm8p.cuh): per-lane DMA offsets are 32-bit
+static bool g8p_fits(int N, int K, bool fp8) {
+    return (static_cast<size_t>(N) + 512) * K * (fp8 ? 1 : 2) < (size_t{1} << 32);
+}
+
 template <bool FP8, bool EPI, int WN>
 static void gemm256_launch_t(const void *x, const void *W, half_t *y, int M, int N, int K, const half_t *bias, const half_t *residual,
                              const float *xscale, const float *wscale, hipStream_t st, int ldc = 0) {
@@ -519,6 +525,31 @@ static void gemm256_launch_t(const void *x, const void *W, half_t *y, int M, int
     }();
     (void)attr_set;
     const int tm = (M + 255) / 256, tn = (N + 64 * WN - 1) / (64 * WN);
+    if constexpr (WN == 4) {
+        if (g8p_fits(N, K, FP8)) {
+            static const bool attr8 = [] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm8p_kernel<FP8, EPI, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+                return true;
+            }();
+            (void)attr8;
+            gemm8p_kernel<FP8, EPI, false><<<tm * tn, 512, lds_bytes, st>>>(x, W, y, M, N, K, bias, residual, tn, xscale, wscale, ldc, g256_group_m());
+            return;
+        }
+    }
+    if constexpr (WN == 2) {
+        if (g8p_fits(N, K, FP8)) {
+            constexpr int ring_bytes = 9 * 128 * 128;
+            static const bool attr8 = [] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm8p_n128_kernel<FP8, EPI>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, ring_bytes);
+                return true;
+            }();
+            (void)attr8;
+            gemm8p_n128_kernel<FP8, EPI><<<tm * tn, 512, ring_bytes, st>>>(x, W, y, M, N, K, bias, residual, tn, xscale, wscale, ldc, g256_group_m());
+            return;
+        }
+    }
     gemm256_kernel<FP8, EPI, WN><<<tm * tn, 512, lds_bytes, st>>>(x, W, y, M, N, K, bias, residual, tn, xscale, wscale, ldc, g256_group_m());
 }
 
@@ -540,6 +571,21 @@ void gemm256_swiglu_launch(bool fp8, const void *x, const void *W, half_t *y, in
     }();
     (void)attr_set;
     const int tm = (M + 255) / 256, tn = (two_inter / 2 + 127) / 128;
+    if (g8p_fits(two_inter, K, fp8)) {
+        static const bool attr8 = [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm8p_kernel<false, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm8p_kernel<true, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            return true;
+        }();
+        (void)attr8;
+        if (fp8)
+            gemm8p_kernel<true, false, true><<<tm * tn, 512, lds_bytes, st>>>(x, W, y, M, two_inter, K, nullptr, nullptr, tn, xscale, wscale, 0, g256_group_m());
+        else
+            gemm8p_kernel<false, false, true><<<tm * tn, 512, lds_bytes, st>>>(x, W, y, M, two_inter, K, nullptr, nullptr, tn, nullptr, nullptr, 0, g256_group_m());
+        return;
+    }
     if (fp8)
         gemm256_kernel<true, false, 4, true><<<tm * tn, 512, lds_bytes, st>>>(x, W, y, M, two_inter, K, nullptr, nullptr, tn, xscale, wscale, 0, g256_group_m());
     else

@@ -10,7 +10,8 @@ lib = llmie.lib()
 dev = "cuda"
 X32 = int(os.environ.get("PK_X32", "0"))   # x32-layout flags of the timed calls (buffers always hold 32 rows)
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-fmt = llmie.W_INT8
+FMT = sys.argv[2] if len(sys.argv) > 2 else "int8"
+fmt = {"int8": llmie.W_INT8, "int4": llmie.W_INT4, "f16": llmie.W_F16}[FMT]
 K = 4096
 
 
@@ -33,10 +34,20 @@ for mode in ("plain", "norm", "resid"):
         NS = max(2, 600 // (N * K // 1000000))
         sets = []
         for _ in range(NS):
-            w = torch.randint(-127, 128, (N, K), dtype=torch.int8, device=dev)
-            sc = torch.full((N,), 0.01, dtype=torch.float16, device=dev)
-            p, _ = llmie.pack_weight(fmt, w, sc, False)
-            sets.append((p, sc))
+            if FMT == "int4":
+                w = torch.randint(0, 256, (N, K // 2), dtype=torch.uint8, device=dev)
+                sc = torch.full((N, K // 128), 0.01, dtype=torch.float16, device=dev)
+                p, ps = llmie.pack_weight(fmt, w, sc, False)
+                sets.append((p, ps))
+            elif FMT == "f16":
+                w = (torch.randn((N, K), device=dev) * 0.02).half()
+                p, _ = llmie.pack_weight(fmt, w, None, False)
+                sets.append((p, None))
+            else:
+                w = torch.randint(-127, 128, (N, K), dtype=torch.int8, device=dev)
+                sc = torch.full((N,), 0.01, dtype=torch.float16, device=dev)
+                p, _ = llmie.pack_weight(fmt, w, sc, False)
+                sets.append((p, sc))
             del w
         y = torch.zeros((32, N), device=dev, dtype=torch.float16)
         st = llmie._st()
@@ -47,6 +58,6 @@ for mode in ("plain", "norm", "resid"):
                                          llmie._p(y) if mode == "resid" else None, llmie._p(gamma) if mode == "norm" else None, None, 1e-5, None, 0, st)
             assert rc == 0, lib.llmie_last_error()
         t = timeit(call, 2 * NS)
-        print("M=%d %-5s tiles/WG=%d  %7.2f us  %5.2f TB/s" % (M, mode, j, t, N * K / t / 1e6), flush=True)
+        print("%s M=%d %-5s tiles/WG=%d  %7.2f us  %5.2f TB/s" % (FMT, M, mode, j, t, N * K * {"int8": 1, "int4": 0.5, "f16": 2}[FMT] / t / 1e6), flush=True)
         del sets
         torch.cuda.empty_cache()
