@@ -579,7 +579,7 @@ def main():
             # dominant prefill kernel: the gate/up projection GEMM with the SwiGLU epilogue (2 * T * 2I * H flops per launch)
             ms_, n_ = pp["gate_up_swiglu"]
             out["roofline_prefill"] = roofline_block(
-                "gemm256 LDS-DMA MFMA kernel, 256 x 256 tiles (gate/up projection + SwiGLU epilogue), T = 2048", "mfma",
+                "gemm8p_kernel<fp16,SwiGLU>: 256 x 256 LDS-DMA MFMA tiles, eight-phase ping-pong schedule (gate/up projection + SwiGLU epilogue), T = 2048", "mfma",
                 2.0 * 2048 * 2 * cfg["inter_size"] * H, ms_ / n_ * 1e3, n_, 2500.0, "TFLOP/s", "prefill_f16_b1_s2048")
             out["roofline_prefill"]["whole_pass"] = dict(extra["prefill_f16_b1_s2048"])
         record_prefill("prefill_f16_b8_s512", 8, 512)

@@ -251,6 +251,32 @@ def test_linear_gemm256(llmie, M, K, N, epi):
         close(host(y), orc.linear(x, w), 2e-3, 2e-3)
 
 
+@pytest.mark.parametrize("M,K,N", [(2048, 4096, 8192), (2048, 4096, 4096), (4096, 2112, 3072), (2000, 11008, 4000), (512, 704, 16384)])
+def test_linear_eight_phase_schedule_race_screen(llmie, M, K, N):
+    """gemm8p.cuh orders its LDS-DMA against its fragment reads by counted vmcnt waits and raw barriers only -- a misplaced wait
+    would show as a rare wrong tile, not as a steady error.  The accumulation order is fixed, so every launch must reproduce the
+    first one bit for bit: 24 launches per shape (256 x 256 and 256 x 128 tiles, even / odd / multiple-of-three k-tile counts,
+    ragged edges), a 512 MiB fill between some of them (cold L2 / Infinity Cache changes the DMA landing order), and the first
+    result checked against the fp32 reference GEMM of the same operands."""
+    g = torch.Generator(device=DEV).manual_seed(M + K + N)
+    x = torch.randn((M, K), device=DEV, generator=g).half()
+    w = (torch.randn((N, K), device=DEV, generator=g) / K ** 0.5).half()
+    y0 = torch.empty((M, N), device=DEV, dtype=torch.float16)
+    llmie.linear(x, w, y0)
+    ref = x[:192].float() @ w.float().t()
+    assert (y0[:192].float() - ref).abs().max().item() < 2e-2
+    ref = x[-64:].float() @ w.float().t()
+    assert (y0[-64:].float() - ref).abs().max().item() < 2e-2
+    junk = torch.empty(1 << 29, dtype=torch.uint8, device=DEV)
+    y = torch.empty_like(y0)
+    for it in range(24):
+        if it % 3 == 0:
+            junk.fill_(it)
+        y.fill_(7.0)
+        llmie.linear(x, w, y)
+        assert torch.equal(y, y0), "launch %d differs from the first in %d elements" % (it, (y != y0).sum().item())
+
+
 @pytest.mark.parametrize("M,K,I", [(4096, 128, 3072), (4000, 192, 3100), (300, 256, 344)])
 def test_linear_swiglu_large_m(llmie, M, K, I):
     """ffn.cpp:105-122 in one launch at prefill sizes: the 256-token tile multiplies 128 gate and the matching 128 up rows
