@@ -36,3 +36,15 @@ def golden():
     import json
     with open(os.path.join(ROOT, "tests", "golden", "known_answers.json")) as f:
         return json.load(f)
+
+
+def systematic_error(got, exp):
+    """(relative Frobenius error, |projection of the error on the expected signal|): element-wise bounds of a few fp16 ulps
+    per stage cannot see a 1 % gain error on a whole layer -- these two can (a scale error s gives a projection of |s|, and
+    both are ~1e-3 for correct fp16 pipelines)"""
+    import numpy as np
+    got = np.asarray(got, np.float64).ravel()
+    exp = np.asarray(exp, np.float64).ravel()
+    den = float(np.dot(exp, exp)) + 1e-30
+    d = got - exp
+    return float(np.sqrt(np.dot(d, d) / den)), abs(float(np.dot(d, exp)) / den)
