@@ -79,14 +79,16 @@ __device__ __forceinline__ float chunk_dot(const uint4_t w, const half8_t (&x)[W
         }
         return acc;
     } else if constexpr (WBITS == 8) {
-        // bytes b0..b3 of a word -> halves (b0,b1), (b2,b3) as 1024 + (b ^ 0x80) = 1152 + int8
-        const half2_t off = {static_cast<half_t>(1152.f), static_cast<half_t>(1152.f)};
+        // bytes b0..b3 of a word -> halves (b0,b1), (b2,b3) as 1024 + (b ^ 0x80) = 1152 + int8, multiplied AS THEY ARE: the
+        // caller starts `acc` at -1152 * (sum of this thread's activation slice), once per token instead of a packed subtract
+        // per weight pair (products of two fp16 values are exact in the fp32 dot; the partial sums stay below 2^24 ulps of
+        // the result's scale: |x| * 1279 * k-slice against fp32's 24 bits)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned int v = w[i] ^ 0x80808080u;
             const unsigned int lo = __builtin_amdgcn_perm(0x64646464u, v, 0x04010400u);  // {0x64,b1,0x64,b0}
             const unsigned int hi = __builtin_amdgcn_perm(0x64646464u, v, 0x04030402u);  // {0x64,b3,0x64,b2}
-            const half2_t wlo = as_half2(lo) - off, whi = as_half2(hi) - off;
+            const half2_t wlo = as_half2(lo), whi = as_half2(hi);
             const half8_t xv = x[i >> 1];
             const int b = (i & 1) * 4;
             acc = __builtin_amdgcn_fdot2(wlo, half2_t{xv[b], xv[b + 1]}, acc, false);
@@ -294,6 +296,22 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
         }
     }
 
+    // int8: chunk_dot<8> multiplies 1152 + w; every dot of this thread starts at -1152 * sum(x slice)
+    float xcorr[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        xcorr[m] = 0.f;
+        if constexpr (WBITS == 8 && !FP8) {
+            float sx = 0.f;
+#pragma unroll
+            for (int j = 0; j < XC; ++j)
+#pragma unroll
+                for (int e = 0; e < XE; ++e)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) sx += to_f32(xr[m][j][e][i]);
+            xcorr[m] = -1152.0f * sx;
+        }
+    }
     auto step = [&](auto &wb, auto &wsc, auto &wbn, auto &wscn, const int cur, const int it) {
         const int nxt = cur + gridDim.x;
         if constexpr (DB) {
@@ -309,7 +327,7 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
             }
 #pragma unroll
             for (int m = 0; m < M; ++m) {
-                float sdot = 0.f;
+                float sdot = xcorr[m];
 #pragma unroll
                 for (int j = 0; j < XC; ++j) {
                     if constexpr (WBITS == 4) sdot = fmaf(sc[j], chunk_dot<4>(wb[r][j], xr[m][j], 0.f), sdot);
