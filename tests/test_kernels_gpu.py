@@ -233,7 +233,11 @@ def test_linear_128_row_splitk(llmie, M, K, N):
 
 @pytest.mark.parametrize("M,K,N,epi", [(4096, 128, 3072, False), (4000, 192, 3100, False), (3900, 256, 3330, True),
                                        (8192, 64, 2048, True), (4096, 192, 1664, False), (4090, 128, 1602, True),
-                                       (2048, 128, 12288, True), (2000, 192, 12200, False)])
+                                       (2048, 128, 12288, True), (2000, 192, 12200, False),
+                                       # k-tile counts that end the eight-phase loops in each of their tails: 5 and 8 k-tiles on
+                                       # the 256-wide kernel (two per loop body), 7 and 8 on the 128-wide one (three per body)
+                                       (4096, 320, 3072, True), (4000, 512, 3100, False), (4096, 448, 1600, False),
+                                       (4090, 512, 1664, True)])
 def test_linear_gemm256(llmie, M, K, N, epi):
     """shapes whose 256 x 256 grid fills the chip (>= 192 tiles) take the LDS-DMA kernel (gemm256.cuh): full tiles,
     ragged M and N edges, odd k-tile counts, bias + in-place residual epilogue; the last two shapes take the two-launch plan

@@ -192,7 +192,8 @@ def test_quantize_fp8_matches_numpy_e4m3(llmie):
 @pytest.mark.parametrize("M,K,N", [(1, 4096, 512), (8, 4096, 1024), (32, 4096, 12288), (64, 11008, 256), (100, 4096, 256),
                                    (300, 512, 384), (4096, 256, 3072), (3990, 640, 3140), (4096, 384, 1600),
                                    (128, 4096, 12288), (70, 11008, 4096), (90, 1024, 8194), (2048, 256, 12288),
-                                   (64, 4096, 12288), (40, 11008, 4096), (48, 1024, 8194)])
+                                   (64, 4096, 12288), (40, 11008, 4096), (48, 1024, 8194),
+                                   (4096, 896, 3072), (4090, 1024, 1664)])   # 7 / 8 k-tiles: the tails of the eight-phase loops
 def test_linear_fp8(llmie, M, K, N):
     rng = np.random.default_rng(52)
     w = _h(rng.standard_normal((N, K)).astype(np.float32) / np.sqrt(K))
