@@ -11,7 +11,9 @@
 //     younger tiles in flight across the one barrier per k-tile, so NS-1 tiles (2 x 32 KiB of weights at WN = 4) are in
 //     flight per CU -- what a bandwidth-bound stream needs;
 //   * 8 waves as 2 (M) x 4 (N), wave tile 64 x 16*WN: L2 activation traffic = |X| per 64*WN weight rows (0.5x the weight stream).
-// LDS stage: X (128 rows x 128 B) | W half 0 | [W half 1], 16 KiB each.
+// LDS stage: X (XR rows x 128 B) | W (64*WN rows x 128 B).  WN = 2, 3 or 4 (128 / 192 / 256 weight rows): the width is chosen so
+// that tiles x K slices come close to the 256 CUs (N = 22016: 115 tiles of 192 rows x 2 slices = 230 workgroups, where 256-row tiles
+// give 172 or 258; N = 12288: 64 x 4 = 256 with one slab less than 48 x 5).
 #pragma once
 #include "device_utils.cuh"
 
@@ -26,13 +28,12 @@ __global__ __launch_bounds__(512) void mid_splitk_kernel(const void *__restrict_
     constexpr int BK = 128 / ES;      // k per tile: rows of 128 bytes either way
     // XR = activation rows staged per k-tile: 128, or 64 for M <= 64 (half the X tile: a 4th stage fits the 160 KiB and
     // three k-tiles of weights stay in flight per CU)
-    constexpr int NHALF = 1 + WN / 2; // halves per stage: X (XR rows), W0, [W1] (128 rows each)
-    constexpr int HALF_BYTES = 128 * 128, X_BYTES = XR * 128, STAGE_BYTES = X_BYTES + (WN / 2) * HALF_BYTES;
+    constexpr int X_BYTES = XR * 128, W_BYTES = 64 * WN * 128, STAGE_BYTES = X_BYTES + W_BYTES;
     constexpr int X_INSTR = XR / 64;  // LDS-DMA instructions per wave for the X tile (8 rows each)
     constexpr int IPT = X_INSTR + WN; // LDS-DMA instructions per wave per k-tile
     constexpr int MI = XR / 32;       // 16-row activation tiles per wave (wave grid 2 x 4)
     static_assert(XR == 128 || XR == 64, "activation rows per stage");
-    static_assert(WN == 2 || WN == 4, "128 or 256 weight rows per workgroup");
+    static_assert(WN >= 2 && WN <= 4, "128, 192 or 256 weight rows per workgroup");
     static_assert(NS >= 2 && (NS - 2) * IPT < 64, "vmcnt is a 6-bit counter");
     const unsigned char *X = static_cast<const unsigned char *>(Xv), *W = static_cast<const unsigned char *>(Wv);
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -46,30 +47,29 @@ __global__ __launch_bounds__(512) void mid_splitk_kernel(const void *__restrict_
 
     // DMA plan (gemm256.cuh): half h, instruction i: this wave fills rows (i*8 + wave)*8 .. +8; lane -> row + lane/8,
     // LDS slot lane%8 receives source chunk slot ^ (row & 7)
-    const unsigned char *src[NHALF][2];
+    // X: instruction i (< X_INSTR) fills X rows (i*8 + wave)*8 .. +8; W: instruction i (< WN) fills W rows (i*8 + wave)*8 .. +8
+    const unsigned char *xsrc[X_INSTR], *wsrc[WN];
 #pragma unroll
-    for (int h = 0; h < NHALF; ++h)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = (i * 8 + wave) * 8 + (lane >> 3), slot = lane & 7, chunk = slot ^ (row & 7);
-            const int grow = h == 0 ? min(min(row, XR - 1), M - 1) : min(n0 + (h - 1) * 128 + row, N - 1);  // clamped rows are never stored
-            src[h][i] = (h == 0 ? X : W) + (static_cast<size_t>(grow) * K + static_cast<size_t>(kt0) * BK) * ES + chunk * 16;
-        }
+    for (int i = 0; i < (X_INSTR > WN ? X_INSTR : WN); ++i) {
+        const int row = (i * 8 + wave) * 8 + (lane >> 3), slot = lane & 7, chunk = slot ^ (row & 7);
+        if (i < X_INSTR)   // clamped rows are never stored
+            xsrc[i] = X + (static_cast<size_t>(min(min(row, XR - 1), M - 1)) * K + static_cast<size_t>(kt0) * BK) * ES + chunk * 16;
+        if (i < WN) wsrc[i] = W + (static_cast<size_t>(min(n0 + row, N - 1)) * K + static_cast<size_t>(kt0) * BK) * ES + chunk * 16;
+    }
     // Workgroups of one K slice run in lock step and a k-tile of 128-byte row pieces at an 8 KiB row pitch lands in ONE L2
     // channel: every workgroup starts its slice at a different k-tile (sum order is irrelevant: fp32 partials), so that the
     // concurrent tiles spread over the channels.
     const int rot = nk > 0 ? (tile * 3 + ks) % nk : 0;
     auto dma_tile = [&](int tt, int stage) {
         const int t = tt + rot < nk ? tt + rot : tt + rot - nk;
+        typedef const __attribute__((address_space(1))) void *gptr_t;
+        typedef __attribute__((address_space(3))) void *lptr_t;
 #pragma unroll
-        for (int h = 0; h < NHALF; ++h)
+        for (int i = 0; i < X_INSTR; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[i] + static_cast<size_t>(t) * 128), (lptr_t)(lds + stage * STAGE_BYTES + (i * 8 + wave) * 1024), 16, 0, 0);
 #pragma unroll
-            for (int i = 0; i < (h == 0 ? X_INSTR : 2); ++i) {
-                unsigned char *dst = lds + stage * STAGE_BYTES + (h == 0 ? 0 : X_BYTES + (h - 1) * HALF_BYTES) + (i * 8 + wave) * 1024;  // wave-uniform
-                typedef const __attribute__((address_space(1))) void *gptr_t;
-                typedef __attribute__((address_space(3))) void *lptr_t;
-                __builtin_amdgcn_global_load_lds((gptr_t)(src[h][i] + static_cast<size_t>(t) * 128), (lptr_t)dst, 16, 0, 0);
-            }
+        for (int i = 0; i < WN; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + static_cast<size_t>(t) * 128), (lptr_t)(lds + stage * STAGE_BYTES + X_BYTES + (i * 8 + wave) * 1024), 16, 0, 0);
     };
 
     floatx4 acc[MI][WN];
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(512) void mid_splitk_kernel(const void *__restrict_
         for (int j = 0; j < WN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     const int wcol = wc * 16 * WN;  // first weight row of this wave inside the workgroup tile
-    const int a_row0 = wr * (XR / 2) + r, b_row0 = (wcol & 127) + r;
-    const unsigned char *a_base = lds, *b_base = lds + X_BYTES + (wcol >> 7) * HALF_BYTES;
+    const int a_row0 = wr * (XR / 2) + r, b_row0 = wcol + r;   // (b_row0 + 16 j) & 7 == r & 7: the swizzle term is per lane
+    const unsigned char *a_base = lds, *b_base = lds + X_BYTES;
     auto frag = [&](const unsigned char *base, int row, int c) {
         return *reinterpret_cast<const half8_t *>(base + row * 128 + ((c ^ (row & 7)) << 4));
     };

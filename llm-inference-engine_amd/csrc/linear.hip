@@ -215,11 +215,22 @@ static SplitKPlan splitk_plan(int wbits, int M, int K, int N) {
     if ((wbits == 16 || wbits == WF_FP8) && (M >= 65 || mid64) && K % 128 == 0 && N >= 128) {
         const bool fp8 = wbits == WF_FP8;
         p.form = mid64 ? 2 : 1;
+        const int KT = K / (fp8 ? 128 : 64);
+        auto slices = [&](int wn) {
+            const int mtiles = (N + 64 * wn - 1) / (64 * wn);
+            int ks = 256 / mtiles;
+            ks = ks < 1 ? 1 : (ks > 8 ? 8 : ks);
+            if (ks > KT / 4) ks = KT / 4 > 0 ? KT / 4 : 1;
+            return ks;
+        };
         p.wn = N >= 8192 ? 4 : 2;   // wide N: 256 weight rows per workgroup
-        const int mtiles = (N + 64 * p.wn - 1) / (64 * p.wn), KT = K / (fp8 ? 128 : 64);
-        int ks = 256 / mtiles;
-        ks = ks < 1 ? 1 : (ks > 8 ? 8 : ks);
-        if (ks > KT / 4) ks = KT / 4 > 0 ? KT / 4 : 1;
+        if (!mid64 && N >= 8192) {
+            // one workgroup per CU: tiles x slices should come close to 256 -- 192-row tiles where they fill the chip better than
+            // 256-row ones (N = 22016: 115 x 2 = 230 against 86 x 2 = 172; N = 12288: 64 x 4 = 256, one slab less than 48 x 5)
+            const int t4 = (N + 255) / 256, t3 = (N + 191) / 192;
+            if (t3 * slices(3) > t4 * slices(4)) p.wn = 3;
+        }
+        const int ks = slices(p.wn);
         p.per = (KT + ks - 1) / ks;
         p.ks = (KT + p.per - 1) / p.per;  // every slice non-empty
         return p;
@@ -275,6 +286,8 @@ int linear_splitk_partial(int wbits, const void *x, const void *W, int M, int K,
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<true, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 16384);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<false, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 16384);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<true, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 16384);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<false, 3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 40960);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<true, 3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 40960);
             return true;
         }();
         (void)attr_set;
@@ -298,6 +311,9 @@ int linear_splitk_partial(int wbits, const void *x, const void *W, int M, int K,
         } else if (wn == 4) {
             if (fp8) mid_splitk_kernel<true, 4, 3><<<mgrid, 512, 3 * 3 * 16384, st>>>(x, W, mslab, M, N, K, ks, per);
             else mid_splitk_kernel<false, 4, 3><<<mgrid, 512, 3 * 3 * 16384, st>>>(x, W, mslab, M, N, K, ks, per);
+        } else if (wn == 3) {
+            if (fp8) mid_splitk_kernel<true, 3, 3><<<mgrid, 512, 3 * 40960, st>>>(x, W, mslab, M, N, K, ks, per);
+            else mid_splitk_kernel<false, 3, 3><<<mgrid, 512, 3 * 40960, st>>>(x, W, mslab, M, N, K, ks, per);
         } else {
             if (fp8) mid_splitk_kernel<true, 2, 4><<<mgrid, 512, 4 * 2 * 16384, st>>>(x, W, mslab, M, N, K, ks, per);
             else mid_splitk_kernel<false, 2, 4><<<mgrid, 512, 4 * 2 * 16384, st>>>(x, W, mslab, M, N, K, ks, per);

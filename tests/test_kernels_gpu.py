@@ -219,6 +219,7 @@ def test_linear(llmie, dtype, M, K, N, trans_b):
 
 
 @pytest.mark.parametrize("M,K,N", [(128, 4096, 12288), (100, 11008, 4096), (96, 4096, 8200), (77, 1024, 8194), (128, 512, 130),
+                                   (128, 4096, 22016), (90, 1024, 22010),   # 192-row tiles (115 x 2 workgroups), ragged last tile
                                    (65, 4096, 22016), (200, 2048, 8448),
                                    (64, 4096, 12288), (33, 11008, 4096), (50, 1024, 8194), (40, 4096, 22016), (64, 512, 130)])
 def test_linear_128_row_splitk(llmie, M, K, N):
