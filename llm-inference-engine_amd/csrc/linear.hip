@@ -224,7 +224,7 @@ static SplitKPlan splitk_plan(int wbits, int M, int K, int N) {
             return ks;
         };
         p.wn = N >= 8192 ? 4 : 2;   // wide N: 256 weight rows per workgroup
-        if (!mid64 && N >= 8192) {
+        if (N >= 8192) {
             // one workgroup per CU: tiles x slices should come close to 256 -- 192-row tiles where they fill the chip better than
             // 256-row ones (N = 22016: 115 x 2 = 230 against 86 x 2 = 172; N = 12288: 64 x 4 = 256, one slab less than 48 x 5)
             const int t4 = (N + 255) / 256, t3 = (N + 191) / 192;
@@ -298,12 +298,17 @@ int linear_splitk_partial(int wbits, const void *x, const void *W, int M, int K,
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<true, 4, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 40960);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<false, 2, 6, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 24576);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<true, 2, 6, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 24576);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<false, 3, 5, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32768);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<true, 3, 5, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32768);
                 return true;
             }();
             (void)attr64;
             if (wn == 4) {
                 if (fp8) mid_splitk_kernel<true, 4, 4, 64><<<mgrid, 512, 4 * 40960, st>>>(x, W, mslab, M, N, K, ks, per);
                 else mid_splitk_kernel<false, 4, 4, 64><<<mgrid, 512, 4 * 40960, st>>>(x, W, mslab, M, N, K, ks, per);
+            } else if (wn == 3) {   // stage = 8 KiB of activations + 24 KiB of weights: five stages fill the 160 KiB exactly
+                if (fp8) mid_splitk_kernel<true, 3, 5, 64><<<mgrid, 512, 5 * 32768, st>>>(x, W, mslab, M, N, K, ks, per);
+                else mid_splitk_kernel<false, 3, 5, 64><<<mgrid, 512, 5 * 32768, st>>>(x, W, mslab, M, N, K, ks, per);
             } else {
                 if (fp8) mid_splitk_kernel<true, 2, 6, 64><<<mgrid, 512, 6 * 24576, st>>>(x, W, mslab, M, N, K, ks, per);
                 else mid_splitk_kernel<false, 2, 6, 64><<<mgrid, 512, 6 * 24576, st>>>(x, W, mslab, M, N, K, ks, per);
