@@ -83,3 +83,21 @@ def test_packed_kernels_do_not_spill():
     bad = [k for k in ks if k["vgpr_spill"] or k["scratch"]]
     assert not bad, bad
     assert all(k["vgpr"] <= 256 for k in ks)
+
+
+def test_eight_phase_gemm_kernels_do_not_spill():
+    """gemm8p.cuh counts its LDS-DMA by hand (inline asm) and runs one 512-thread workgroup per CU, 2 waves per
+    SIMD: every instantiation (fp16 / e4m3, with and without epilogue, SwiGLU, both tile widths) must fit 256 VGPRs without
+    scratch -- a spill adds VMEM operations the counted waits do not know about, and the e4m3 forms did spill before their MFMAs
+    were pinned in place."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("ckr", os.path.join(root, "tools", "check_kernel_resources.py"))
+    ckr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ckr)
+    obj = os.path.join(root, "llm-inference-engine_amd", "csrc", "_obj", "linear.hip.o")
+    ks = [k for k in ckr.kernel_metadata(obj) if "gemm8p" in k["name"]]
+    assert len(ks) >= 10, [k["name"] for k in ks]
+    bad = [k for k in ks if k["vgpr_spill"] or k["scratch"] or k["vgpr"] > 256]
+    assert not bad, bad
