@@ -97,19 +97,19 @@ __device__ __forceinline__ float chunk_dot(const uint4_t w, const half8_t (&x)[W
         return acc;
     } else {
         // word i holds k = 8i..8i+7 as nibbles n0..n7.  (w & 0x000F000F)|0x6400.. = (1024+n0, 1024+n4); the nibbles at
-        // bits 4-7 land 4 mantissa bits higher: (w & 0x00F000F0)|0x6400.. = (1024+16 n1, 1024+16 n5), brought back with
-        // one packed fma (x/16 - 72 = n - 8, exact); one shift by 8 exposes n2,n6 / n3,n7 to the same two masks.
-        const half2_t off = {static_cast<half_t>(1032.f), static_cast<half_t>(1032.f)};
-        const half2_t sixteenth = {static_cast<half_t>(0.0625f), static_cast<half_t>(0.0625f)};
-        const half2_t off72 = {static_cast<half_t>(72.f), static_cast<half_t>(72.f)};
+        // bits 4-7 land 4 mantissa bits higher: (w & 0x00F000F0)|0x6400.. = (1024+16 n1, 1024+16 n5); one shift by 8 exposes
+        // n2,n6 / n3,n7 to the same two masks.  The halves are multiplied AS THEY ARE: the caller has divided the activations that
+        // meet the 16 n halves by 16 (prescale_x_int4) and starts `acc` at the matching offset term (int4_offset_term), so the
+        // "- 8" of every nibble costs one fp32 term per 32-weight chunk and token instead of a packed subtract / fma per weight
+        // pair -- the GEMV is VALU-bound in this format (profiles/r02_int4_int8_valu_pmc.csv).
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const half8_t xv = x[i];  // permuted: (k0,k4,k1,k5,k2,k6,k3,k7) of this word
+            const half8_t xv = x[i];  // permuted and prescaled: (k0,k4,k1/16,k5/16,k2,k6,k3/16,k7/16) of this word
             const unsigned int w0 = w[i], w8 = w[i] >> 8;
-            const half2_t h0 = as_half2((w0 & 0x000F000Fu) | 0x64006400u) - off;
-            const half2_t h1 = as_half2((w0 & 0x00F000F0u) | 0x64006400u) * sixteenth - off72;
-            const half2_t h2 = as_half2((w8 & 0x000F000Fu) | 0x64006400u) - off;
-            const half2_t h3 = as_half2((w8 & 0x00F000F0u) | 0x64006400u) * sixteenth - off72;
+            const half2_t h0 = as_half2((w0 & 0x000F000Fu) | 0x64006400u);
+            const half2_t h1 = as_half2((w0 & 0x00F000F0u) | 0x64006400u);
+            const half2_t h2 = as_half2((w8 & 0x000F000Fu) | 0x64006400u);
+            const half2_t h3 = as_half2((w8 & 0x00F000F0u) | 0x64006400u);
             acc = __builtin_amdgcn_fdot2(h0, half2_t{xv[0], xv[1]}, acc, false);
             acc = __builtin_amdgcn_fdot2(h1, half2_t{xv[2], xv[3]}, acc, false);
             acc = __builtin_amdgcn_fdot2(h2, half2_t{xv[4], xv[5]}, acc, false);
@@ -117,6 +117,19 @@ __device__ __forceinline__ float chunk_dot(const uint4_t w, const half8_t (&x)[W
         }
         return acc;
     }
+}
+// activation order matching chunk_dot<4>: within each group of 8: (0,4,1,5,2,6,3,7); the elements that meet the nibbles read as
+// 1024 + 16 n (k1, k5, k3, k7) are divided by 16 (exact in fp16 above 2^-10; smaller activations round in the subnormal range)
+__device__ __forceinline__ half8_t prescale_x_int4(const half8_t v) {
+    const float s = 0.0625f;
+    return half8_t{v[0], v[1], from_f32<half_t>(to_f32(v[2]) * s), from_f32<half_t>(to_f32(v[3]) * s),
+                   v[4], v[5], from_f32<half_t>(to_f32(v[6]) * s), from_f32<half_t>(to_f32(v[7]) * s)};
+}
+// sum over one 8-weight word of what chunk_dot<4> adds beyond x . (n - 8): (1024 + 8) x for the plain halves, (64 + 8) x =
+// 1152 (x / 16) for the prescaled ones; the negative of the chunk's total is the start value of its dot
+__device__ __forceinline__ float int4_offset_term(const half8_t v) {
+    return 1032.0f * (to_f32(v[0]) + to_f32(v[1]) + to_f32(v[4]) + to_f32(v[5])) +
+           1152.0f * (to_f32(v[2]) + to_f32(v[3]) + to_f32(v[6]) + to_f32(v[7]));
 }
 // activation order matching chunk_dot<4>: within each group of 8: (0,4,1,5,2,6,3,7)
 __device__ __forceinline__ half8_t permute_x_int4(const half8_t v) {
@@ -135,7 +148,10 @@ __device__ __forceinline__ half8_t permute_x_int4(const half8_t v) {
 // FP8 (WBITS == 8): e4m3 weights with fp32 per-row scales, and the activation row is quantised per token to the e4m3
 // grid in the prologue (scale amax/448, exactly quantize_rows_fp8_kernel's arithmetic) so that the result equals the
 // fp8 MFMA path's  wscale[n] * xscale[m] * sum_k Wq[n,k] xq[m,k]  up to summation order.
-template <int M, int RPW, int XC, int WBITS, bool DB = false, bool FP8 = false>
+// RI = rows per workgroup instruction: a row of at most 2 KiB (int4 at K = 4096: 128 chunks) would leave half of the 256 threads
+// multiplying a clamped chunk with zero activations -- with RI = 2 the two 128-thread halves of the workgroup stream two
+// CONSECUTIVE rows (still one contiguous 4-KiB instruction), waves 0-1 reduce the even row and waves 2-3 the odd one.
+template <int M, int RPW, int XC, int WBITS, bool DB = false, bool FP8 = false, int RI = 1>
 __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
     // DB (quantised weights): two weight register sets -- the next group's loads are issued BEFORE the current group's
     // de-quantise + dot phase (~2 us of VALU per group for int4), which would otherwise run with nothing in flight.
@@ -148,14 +164,17 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
     const int nch = K / EPC;              // chunks per row
     const int nx8 = K >> 3;               // half8 per activation row
     const size_t row_bytes = static_cast<size_t>(K) * WBITS / 8;
+    static_assert(RI == 1 || (RI == 2 && XC == 1), "two rows per instruction: single-chunk rows only");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int TPR = 256 / RI, WPR = 4 / RI;   // threads / waves per row
+    const int sub = tid / TPR, ct = tid % TPR;    // which row of the instruction, chunk index inside the row
     const bool swiglu = a.epi == EPI_SWIGLU;
     const int half_n = N >> 1;
     const int out_n = swiglu ? half_n : N;
-    // a group = RPW rows: EPI_NONE rows [g*RPW, g*RPW+RPW); SWIGLU RPW/2 gate rows + their up rows
-    const int ngroups = swiglu ? (half_n + RPW / 2 - 1) / (RPW / 2) : (N + RPW - 1) / RPW;
+    // a group = RPW instructions of RI rows: EPI_NONE rows [g*RPW*RI, ...); SWIGLU RPW/2 instructions of gate rows + their up rows
+    const int ngroups = swiglu ? (half_n + (RPW / 2) * RI - 1) / ((RPW / 2) * RI) : (N + RPW * RI - 1) / (RPW * RI);
     auto row_of = [&](int grp, int r) {
-        int row = swiglu ? grp * (RPW / 2) + (r >> 1) + (r & 1) * half_n : grp * RPW + r;
+        int row = swiglu ? (grp * (RPW / 2) + (r >> 1)) * RI + sub + (r & 1) * half_n : (grp * RPW + r) * RI + sub;
         const int lim = swiglu ? ((r & 1) ? N : half_n) : N;
         return row < lim ? row : lim - 1;  // clamp: result of a clamped row is never stored
     };
@@ -167,7 +186,7 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
     for (int m = 0; m < M; ++m)
 #pragma unroll
         for (int j = 0; j < XC; ++j) {
-            const int cc = j * 256 + tid;
+            const int cc = j * 256 + ct;
 #pragma unroll
             for (int e = 0; e < XE; ++e)
                 xr[m][j][e] = cc < nch ? xg[m * nx8 + cc * XE + e] : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
@@ -177,7 +196,7 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
         const half8_t *gm = reinterpret_cast<const half8_t *>(a.gamma);
 #pragma unroll
         for (int j = 0; j < XC; ++j) {
-            const int cc = j * 256 + tid;
+            const int cc = j * 256 + ct;
 #pragma unroll
             for (int e = 0; e < XE; ++e) g[j][e] = cc < nch ? gm[cc * XE + e] : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
         }
@@ -197,13 +216,13 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
                 // the scale's L2 round trip overlaps the HBM one instead of following it
                 const half_t *srow = scale + static_cast<size_t>(row_of(grp, r)) * sgroups;
 #pragma unroll
-                for (int j = 0; j < XC; ++j) wsc[r][j] = srow[(min(j * 256 + tid, nch - 1) * EPC) / a.group];
+                for (int j = 0; j < XC; ++j) wsc[r][j] = srow[(min(j * 256 + ct, nch - 1) * EPC) / a.group];
             }
 #pragma unroll
             for (int j = 0; j < XC; ++j) {
                 // unconditional load (a predicated one would put every load in its own exec-masked region); chunks past
                 // the row end re-read the last chunk and meet an all-zero activation slice
-                const int cc = min(j * 256 + tid, nch - 1);
+                const int cc = min(j * 256 + ct, nch - 1);
                 wb[r][j] = load_nt(w + cc);
             }
         }
@@ -216,7 +235,7 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
         if (pb) {
 #pragma unroll
             for (int j = 0; j < XC; ++j) {
-                const int cc = j * 256 + tid;
+                const int cc = j * 256 + ct;
                 if (cc < nch) {
 #pragma unroll
                     for (int e = 0; e < XE; ++e) {
@@ -242,7 +261,7 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
         __syncthreads();
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-            const float inv = rsqrtf((ssq[0][m] + ssq[1][m] + ssq[2][m] + ssq[3][m]) / static_cast<float>(K) + a.eps);
+            const float inv = rsqrtf((RI == 1 ? ssq[0][m] + ssq[1][m] + ssq[2][m] + ssq[3][m] : ssq[0][m] + ssq[1][m]) / static_cast<float>(K) + a.eps);   // RI = 2: both halves hold the whole row
 #pragma unroll
             for (int j = 0; j < XC; ++j)
 #pragma unroll
@@ -258,7 +277,19 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
 #pragma unroll
             for (int j = 0; j < XC; ++j)
 #pragma unroll
-                for (int e = 0; e < XE; ++e) xr[m][j][e] = permute_x_int4(xr[m][j][e]);
+                for (int e = 0; e < XE; ++e) xr[m][j][e] = prescale_x_int4(permute_x_int4(xr[m][j][e]));
+    }
+    float xcorr4[WBITS == 4 ? M : 1][WBITS == 4 ? XC : 1];   // int4: start value of every 32-weight chunk's dot
+    if constexpr (WBITS == 4) {
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+#pragma unroll
+            for (int j = 0; j < XC; ++j) {
+                float t = 0.f;
+#pragma unroll
+                for (int e = 0; e < XE; ++e) t += int4_offset_term(xr[m][j][e]);
+                xcorr4[m][j] = -t;
+            }
     }
     __shared__ float amx[FP8 ? 4 : 1][M], xscale_sh[M];  // FP8: per-token activation amax / scale
     if constexpr (FP8) {
@@ -330,7 +361,7 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
                 float sdot = xcorr[m];
 #pragma unroll
                 for (int j = 0; j < XC; ++j) {
-                    if constexpr (WBITS == 4) sdot = fmaf(sc[j], chunk_dot<4>(wb[r][j], xr[m][j], 0.f), sdot);
+                    if constexpr (WBITS == 4) sdot = fmaf(sc[j], chunk_dot<4>(wb[r][j], xr[m][j], xcorr4[m][j]), sdot);
                     else sdot = chunk_dot<WBITS, FP8>(wb[r][j], xr[m][j], sdot);
                 }
                 acc[m][r] = sdot;
@@ -356,16 +387,17 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
             if constexpr (FP8) return reinterpret_cast<const float *>(a.scale)[row];
             else return (WBITS == 8) ? to_f32(scale[row]) : 1.0f;
         };
+        // row h (< RI) of instruction r was summed by waves h*WPR .. h*WPR + WPR - 1
         if (swiglu) {
-            if (tid < M * (RPW / 2)) {
-                const int m = tid / (RPW / 2), q = tid % (RPW / 2);
-                const int col = cur * (RPW / 2) + q;
+            if (tid < M * (RPW / 2) * RI) {
+                const int m = tid / ((RPW / 2) * RI), qh = tid % ((RPW / 2) * RI), q = qh / RI, h = qh % RI;
+                const int col = (cur * (RPW / 2) + q) * RI + h;
                 if (col < half_n) {
                     float gt = 0.f, up = 0.f;
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        gt += slot[w * (M * RPW) + m * RPW + 2 * q];
-                        up += slot[w * (M * RPW) + m * RPW + 2 * q + 1];
+                    for (int w = 0; w < WPR; ++w) {
+                        gt += slot[(h * WPR + w) * (M * RPW) + m * RPW + 2 * q];
+                        up += slot[(h * WPR + w) * (M * RPW) + m * RPW + 2 * q + 1];
                     }
                     gt *= row_scale(col) * (FP8 ? xscale_sh[m] : 1.0f);
                     up *= row_scale(col + half_n) * (FP8 ? xscale_sh[m] : 1.0f);
@@ -373,13 +405,13 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvArgs a) {
                 }
             }
         } else {
-            if (tid < M * RPW) {
-                const int m = tid / RPW, r = tid % RPW;
-                const int col = cur * RPW + r;
+            if (tid < M * RPW * RI) {
+                const int m = tid / (RPW * RI), rh = tid % (RPW * RI), r = rh / RI, h = rh % RI;
+                const int col = (cur * RPW + r) * RI + h;
                 if (col < N) {
                     float v = 0.f;
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) v += slot[w * (M * RPW) + m * RPW + r];
+                    for (int w = 0; w < WPR; ++w) v += slot[(h * WPR + w) * (M * RPW) + m * RPW + r];
                     v *= row_scale(col) * (FP8 ? xscale_sh[m] : 1.0f);
                     if (a.bias) v += to_f32(a.bias[col]);
                     if (a.residual) v += to_f32(a.residual[static_cast<size_t>(m) * N + col]);

@@ -12,14 +12,14 @@ namespace llmie {
 // ---- decode GEMV dispatch ----
 // K-split kernel: XC = 16-byte chunks per thread = ceil(K*WBITS/128/256) rounded up to {1,2,3,4,6,8}; RPW rows per
 // iteration so that RPW*XC ~ 16 loads are in flight per lane; register budget M*XC*XE <= 16 half8 of activations.
-template <int M, int RPW, int XC, int WBITS, bool DB = false, bool FP8 = false> static void launch_ksplit(const GemvArgs &a, hipStream_t st) {
+template <int M, int RPW, int XC, int WBITS, bool DB = false, bool FP8 = false, int RI = 1> static void launch_ksplit(const GemvArgs &a, hipStream_t st) {
     const bool swiglu = a.epi == EPI_SWIGLU;
-    const int groups = swiglu ? (a.N / 2 + RPW / 2 - 1) / (RPW / 2) : (a.N + RPW - 1) / RPW;
+    const int groups = swiglu ? (a.N / 2 + (RPW / 2) * RI - 1) / ((RPW / 2) * RI) : (a.N + RPW * RI - 1) / (RPW * RI);
     // long-lived workgroups (the prologue -- activation slice + norm -- is paid once per workgroup), evenly loaded
     constexpr int target = 768;
     const int iters = (groups + target - 1) / target;
     const int grid = (groups + iters - 1) / iters;
-    gemv_ksplit_kernel<M, RPW, XC, WBITS, DB, FP8><<<grid, 256, 0, st>>>(a);
+    gemv_ksplit_kernel<M, RPW, XC, WBITS, DB, FP8, RI><<<grid, 256, 0, st>>>(a);
 }
 
 static int ksplit_xc(int K, int wbits) { return (K * wbits / 128 + 255) / 256; }
@@ -29,6 +29,13 @@ template <int M, int WBITS, bool FP8 = false> static bool dispatch_ksplit(const 
     const int xc = ksplit_xc(a.K, WBITS);
     if constexpr (M * 1 * XE <= 16) {
         if (xc <= 1) {  // quantised rows are short: 8 rows per group, double buffered (16 loads in flight per lane)
+            if constexpr (WBITS == 4) {
+                // rows of at most 2 KiB (K <= 4096): two consecutive rows per workgroup instruction, or half the threads idle
+                if (a.K * WBITS / 128 <= 128 && (a.epi != EPI_SWIGLU || (a.N / 2) % 2 == 0)) {
+                    launch_ksplit<M, 8, 1, WBITS, true, FP8, 2>(a, st);
+                    return true;
+                }
+            }
             if constexpr (WBITS == 16) launch_ksplit<M, 8, 1, 16>(a, st);
             else launch_ksplit<M, 8, 1, WBITS, true, FP8>(a, st);
             return true;

@@ -71,7 +71,10 @@ def test_linear_w8a16(llmie, M, K, N):
 
 
 @pytest.mark.parametrize("M,K,N,group", [(11, 4096, 512, 128), (37, 11008, 256, 128), (64, 4096, 1000, 128), (100, 11008, 4096, 128), (20, 4096, 22016, 128), (1, 4096, 512, 128), (2, 4096, 22016, 128), (4, 4096, 256, 128),
-                                         (1, 11008, 4096, 128), (2, 11008, 128, 128), (1, 128, 64, 32)])
+                                         (1, 11008, 4096, 128), (2, 11008, 128, 128), (1, 128, 64, 32),
+                                         # rows of <= 2 KiB: two consecutive rows per workgroup instruction (odd N, a last group with
+                                         # one row, rows shorter than the 128 threads of a half, three tokens)
+                                         (1, 4096, 4097, 128), (3, 4096, 1003, 128), (2, 2048, 513, 128), (1, 1024, 77, 64)])
 def test_linear_w4a16(llmie, M, K, N, group):
     rng = np.random.default_rng(33)
     w = rng.standard_normal((N, K)).astype(np.float32) / np.sqrt(K)
