@@ -27,6 +27,12 @@ def test_linear_workspace_query_follows_the_split_k_plans(llmie, lib):
             assert m * 12288 * 4 <= b <= 16 * m * 12288 * 4, (fmt, m, b)
             assert b >= prev or m in (33, 65), (fmt, m)   # (a different kernel form starts at 33 and 65 rows: fewer, larger slices)
             prev = b
+    # 128-row kernel: the tile width follows the chip fill -- 192-row tiles for the 7B gate/up (115 x 2 slices) and QKV (64 x 4)
+    # projections, 128-row tiles for the 4096-wide ones (32 x 8)
+    assert q(F16, 128, 4096, 22016) == 2 * 128 * 22016 * 4
+    assert q(F16, 128, 4096, 12288) == 4 * 128 * 12288 * 4
+    assert q(F16, 128, 4096, 4096) == 8 * 128 * 4096 * 4
+    assert q(F16, 64, 4096, 22016) == 2 * 64 * 22016 * 4
     # more than one pass of 128 rows reuses the same slabs
     assert q(I8, 500, 4096, 4096) == q(I8, 128, 4096, 4096)
     # garbage in, zero out
