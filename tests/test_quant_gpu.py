@@ -74,7 +74,8 @@ def test_linear_w8a16(llmie, M, K, N):
                                          (1, 11008, 4096, 128), (2, 11008, 128, 128), (1, 128, 64, 32),
                                          # rows of <= 2 KiB: two consecutive rows per workgroup instruction (odd N, a last group with
                                          # one row, rows shorter than the 128 threads of a half, three tokens)
-                                         (1, 4096, 4097, 128), (3, 4096, 1003, 128), (2, 2048, 513, 128), (1, 1024, 77, 64)])
+                                         (1, 4096, 4097, 128), (3, 4096, 1003, 128), (2, 2048, 513, 128), (1, 1024, 77, 64),
+                                         (1, 11008, 4097, 128), (1, 5120, 301, 128)])
 def test_linear_w4a16(llmie, M, K, N, group):
     rng = np.random.default_rng(33)
     w = rng.standard_normal((N, K)).astype(np.float32) / np.sqrt(K)
