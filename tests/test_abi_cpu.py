@@ -99,5 +99,5 @@ def test_eight_phase_gemm_kernels_do_not_spill():
     obj = os.path.join(root, "llm-inference-engine_amd", "csrc", "_obj", "linear.hip.o")
     ks = [k for k in ckr.kernel_metadata(obj) if "gemm8p" in k["name"]]
     assert len(ks) >= 10, [k["name"] for k in ks]
-    bad = [k for k in ks if k["vgpr_spill"] or k["scratch"] or k["vgpr"] > 256]
+    bad = [k for k in ks if k["vgpr_spill"] or k["sgpr_spill"] or k["scratch"] or k["vgpr"] > 256]
     assert not bad, bad
