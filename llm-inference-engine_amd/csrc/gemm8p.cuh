@@ -29,10 +29,12 @@ namespace llmie {
 
 __device__ __forceinline__ void g8_dma16(const unsigned voff, const void *sbase, const unsigned lds_dst) {
     // 1 KiB per wave: 16 bytes per lane from sbase + voff -> LDS lds_dst + 16 lane (M0 written in the statement that uses it).
-    // The leading s_nop 4: hipcc pads no hazard inside an asm string, and "VALU writes SGPR -> VMEM reads it" (an SGPR restored
-    // from a spill lane with v_readlane right in front of the statement) needs 5 wait states (pk_gemm.cuh met exactly that);
-    // no instantiation spills SGPRs today (tests/test_abi_cpu.py), the pad keeps a future one from reading a stale base.
-    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    // hipcc pads no hazard inside an asm string: "VALU writes SGPR -> VMEM reads it" needs 5 wait states, which matters only if
+    // the base pair were produced by a VALU instruction right in front of the statement -- an SGPR restored from a spill lane
+    // with v_readlane (pk_gemm.cuh met exactly that).  Here the base comes out of scalar adds, and tests/test_abi_cpu.py refuses
+    // any instantiation that spills SGPRs; a leading `s_nop 4` as in pk_gemm.cuh was measured and costs 2-13 % of the kernel
+    // (the statement sits in the issue stream of the reading group of every phase), so the guard test stands in for it.
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 // one operand fragment of a k-tile: fp16 -> the two 32-deep k-steps, e4m3 -> one 128-deep step (8 registers the MFMA takes whole)
 template <bool FP8> struct G8Frag;

@@ -6,6 +6,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 spec = importlib.util.spec_from_file_location("llmie_amd", os.path.join(ROOT, "llm-inference-engine_amd", "__init__.py"))
 llmie = importlib.util.module_from_spec(spec); sys.modules["llmie_amd"] = llmie; spec.loader.exec_module(llmie)
+if os.environ.get("LLMIE_LIB"):   # another build of the library (A/B of one kernel change in one gpurun call)
+    llmie.LIB_PATH = os.environ["LLMIE_LIB"]
 
 
 def timed(fn, reps=10):
