@@ -203,21 +203,27 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void *__restrict__ Xv
     if (wr == 1) __builtin_amdgcn_s_barrier();   // the second wave row runs one barrier behind from here on
     asm volatile("" ::: "memory");
 
-    // phase S (0..7) of the two-k-tile loop body: k-tile u (parity S / 4), quadrant S % 4
-    auto phase = [&](auto S_, int u) {
+    // phase S (0..7) of the two-k-tile loop body: k-tile u (parity S / 4), quadrant S % 4.  STEADY (a compile-time fact of the
+    // call): at least four k-tiles are left, so every piece this phase reads or issues exists and five groups stay in flight -- no
+    // tail tests and no wait selection in the instruction stream of the reading group, which is on the critical path of every
+    // phase (ten extra scalar wait cycles per phase were measured at 2-13 % of the kernel).
+    auto phase = [&](auto S_, int u, auto steady_) {
         constexpr int S = decltype(S_)::value, s = S & 3;
         constexpr unsigned par = S >> 2;
+        constexpr bool STEADY = decltype(steady_)::value;
         // reads of this phase's new piece (group 4u + s + 1)
         if constexpr (s == 0) read_a(par, 0);
         else if constexpr (s == 1) read_b(par, 1, fb1);
         else if constexpr (s == 2) read_a(par, 1);
-        else if (u + 1 < KT) read_b(par ^ 1, 0, fb0[par ^ 1]);
+        else if (STEADY || u + 1 < KT) read_b(par ^ 1, 0, fb0[par ^ 1]);
         // DMA group 4u + s + 7
-        if constexpr (s == 0) { if (u + 1 < KT) issue(K3{}, u + 1, par ^ 1); }
-        else if constexpr (s == 1) { if (u + 2 < KT) issue(K1{}, u + 2, par); }
-        else if constexpr (s == 2) { if (u + 2 < KT) issue(K0{}, u + 2, par); }
-        else { if (u + 2 < KT) issue(K2{}, u + 2, par); }
-        g8_wait_groups(G - (4 * u + s) - 3);   // group 4u + s + 2 landed: the next phase reads it
+        if constexpr (s == 0) { if (STEADY || u + 1 < KT) issue(K3{}, u + 1, par ^ 1); }
+        else if constexpr (s == 1) { if (STEADY || u + 2 < KT) issue(K1{}, u + 2, par); }
+        else if constexpr (s == 2) { if (STEADY || u + 2 < KT) issue(K0{}, u + 2, par); }
+        else { if (STEADY || u + 2 < KT) issue(K2{}, u + 2, par); }
+        // group 4u + s + 2 landed: the next phase reads it
+        if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else g8_wait_groups(G - (4 * u + s) - 3);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -232,16 +238,22 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void *__restrict__ Xv
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
+    auto body = [&](int u, auto steady_) {
+        phase(std::integral_constant<int, 0>{}, u, steady_); phase(std::integral_constant<int, 1>{}, u, steady_);
+        phase(std::integral_constant<int, 2>{}, u, steady_); phase(std::integral_constant<int, 3>{}, u, steady_);
+        phase(std::integral_constant<int, 4>{}, u + 1, steady_); phase(std::integral_constant<int, 5>{}, u + 1, steady_);
+        phase(std::integral_constant<int, 6>{}, u + 1, steady_); phase(std::integral_constant<int, 7>{}, u + 1, steady_);
+    };
     int u = 0;
-    for (; u + 1 < KT; u += 2) {
-        phase(std::integral_constant<int, 0>{}, u); phase(std::integral_constant<int, 1>{}, u);
-        phase(std::integral_constant<int, 2>{}, u); phase(std::integral_constant<int, 3>{}, u);
-        phase(std::integral_constant<int, 4>{}, u + 1); phase(std::integral_constant<int, 5>{}, u + 1);
-        phase(std::integral_constant<int, 6>{}, u + 1); phase(std::integral_constant<int, 7>{}, u + 1);
+    // steady bodies: k-tiles u and u + 1 with KT - (u + 1) >= 3 (phase 4(u+1) + 3 still waits with five groups behind it: 4 KT -
+    // (4(u+1) + 3) - 3 >= 5; its issue of k-tile u + 3 exists)
+    if constexpr (!(FP8 && SWIGLU)) {   // (the e4m3 SwiGLU form with both bodies spills two registers: it keeps the generic body)
+        for (; u + 3 < KT; u += 2) body(u, std::true_type{});
     }
+    for (; u + 1 < KT; u += 2) body(u, std::false_type{});
     if (u < KT) {   // odd number of k-tiles: the last one has even parity
-        phase(std::integral_constant<int, 0>{}, u); phase(std::integral_constant<int, 1>{}, u);
-        phase(std::integral_constant<int, 2>{}, u); phase(std::integral_constant<int, 3>{}, u);
+        phase(std::integral_constant<int, 0>{}, u, std::false_type{}); phase(std::integral_constant<int, 1>{}, u, std::false_type{});
+        phase(std::integral_constant<int, 2>{}, u, std::false_type{}); phase(std::integral_constant<int, 3>{}, u, std::false_type{});
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with the second row's last barrier
 
@@ -372,20 +384,24 @@ __global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict
     if (wr == 1) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    // phase S (0..5) of the three-k-tile loop body: k-tile u with u % 3 = S / 2
-    auto phase = [&](auto S_, int u) {
+    // phase S (0..5) of the three-k-tile loop body: k-tile u with u % 3 = S / 2; STEADY as in gemm8p_kernel (at least four k-tiles
+    // left: every piece exists, 4 / 5 groups stay in flight)
+    auto phase = [&](auto S_, int u, auto steady_) {
         constexpr int S = decltype(S_)::value, s = S & 1;
         constexpr unsigned c = S >> 1, c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+        constexpr bool STEADY = decltype(steady_)::value;
         if constexpr (s == 0) {
             read_a(3 * c + 1);
-            if (u + 2 < KT) issue(K1{}, u + 2, 3 * c2 + 1);
-            g8_wait_instrs(2 * min(4, G - 3 * u - 4));
+            if (STEADY || u + 2 < KT) issue(K1{}, u + 2, 3 * c2 + 1);
+            if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else g8_wait_instrs(2 * min(4, G - 3 * u - 4));
         } else {
             read_a(3 * c + 2);
-            if (u + 1 < KT) read_b(3 * c1, fb[c1]);
-            if (u + 2 < KT) issue(K2{}, u + 2, 3 * c2 + 2);
-            if (u + 3 < KT) issue(K0{}, u + 3, 3 * c);
-            g8_wait_instrs(2 * min(5, G - 3 * u - 5));
+            if (STEADY || u + 1 < KT) read_b(3 * c1, fb[c1]);
+            if (STEADY || u + 2 < KT) issue(K2{}, u + 2, 3 * c2 + 2);
+            if (STEADY || u + 3 < KT) issue(K0{}, u + 3, 3 * c);
+            if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else g8_wait_instrs(2 * min(5, G - 3 * u - 5));
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -399,14 +415,16 @@ __global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
+    auto body = [&](int u, auto steady_) {
+        phase(std::integral_constant<int, 0>{}, u, steady_); phase(std::integral_constant<int, 1>{}, u, steady_);
+        phase(std::integral_constant<int, 2>{}, u + 1, steady_); phase(std::integral_constant<int, 3>{}, u + 1, steady_);
+        phase(std::integral_constant<int, 4>{}, u + 2, steady_); phase(std::integral_constant<int, 5>{}, u + 2, steady_);
+    };
     int u = 0;
-    for (; u + 2 < KT; u += 3) {
-        phase(std::integral_constant<int, 0>{}, u); phase(std::integral_constant<int, 1>{}, u);
-        phase(std::integral_constant<int, 2>{}, u + 1); phase(std::integral_constant<int, 3>{}, u + 1);
-        phase(std::integral_constant<int, 4>{}, u + 2); phase(std::integral_constant<int, 5>{}, u + 2);
-    }
-    if (u < KT) { phase(std::integral_constant<int, 0>{}, u); phase(std::integral_constant<int, 1>{}, u); }
-    if (u + 1 < KT) { phase(std::integral_constant<int, 2>{}, u + 1); phase(std::integral_constant<int, 3>{}, u + 1); }
+    for (; u + 5 < KT; u += 3) body(u, std::true_type{});    // KT - (u + 2) >= 4
+    for (; u + 2 < KT; u += 3) body(u, std::false_type{});
+    if (u < KT) { phase(std::integral_constant<int, 0>{}, u, std::false_type{}); phase(std::integral_constant<int, 1>{}, u, std::false_type{}); }
+    if (u + 1 < KT) { phase(std::integral_constant<int, 2>{}, u + 1, std::false_type{}); phase(std::integral_constant<int, 3>{}, u + 1, std::false_type{}); }
     if (wr == 0) __builtin_amdgcn_s_barrier();
 
     g256_store<FP8, HAS_EPI, 2, false>(acc, C, M, N, ldc, m0, n0, wr, wcol, r, q, bias, residual, xscale, wscale);
