@@ -30,18 +30,18 @@ __device__ __forceinline__ void g256_store(floatx4 (&acc)[8][WN], half_t *C, int
                                            const float *__restrict__ xscale, const float *__restrict__ wscale) {
     const int half_n = N >> 1;
     if constexpr (SWIGLU) {
-        // acc[i][jj] = gate, acc[i][2 + jj] = up of C columns n0 + wcol + 16 jj + 4q + e
+        // acc[i][jj] = gate, acc[i][WN / 2 + jj] = up of C columns n0 + wcol + 16 jj + 4q + e
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int m = m0 + wr * 128 + i * 16 + r;
             if (m >= M) continue;
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
+            for (int jj = 0; jj < WN / 2; ++jj) {
                 const int n = n0 + wcol + jj * 16 + 4 * q;
                 float o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float gt = acc[i][jj][e], up = acc[i][2 + jj][e];
+                    float gt = acc[i][jj][e], up = acc[i][WN / 2 + jj][e];
                     if constexpr (FP8) {
                         const float xsm = xscale[m];
                         gt *= wscale[min(n + e, half_n - 1)] * xsm;

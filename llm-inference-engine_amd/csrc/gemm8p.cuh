@@ -77,7 +77,8 @@ template <bool FP8, bool HAS_EPI, bool SWIGLU = false>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const void *__restrict__ Xv, const void *__restrict__ Wv, half_t *C, int M, int N,
                                                      int K, const half_t *__restrict__ bias, const half_t *residual, int tiles_n,
                                                      const float *__restrict__ xscale, const float *__restrict__ wscale,
-                                                     int ldc_arg = 0, int group_m = 0) {
+                                                     int ldc_arg = 0, int group_m = 0, int col0 = 0) {
+    // col0 (SwiGLU form): first output column of this launch's range (a launch over columns [col0, col0 + tiles_n * 128) of C[M, I])
     static_assert(!SWIGLU || !HAS_EPI, "SwiGLU form: no bias / residual");
     const size_t ldc = ldc_arg ? ldc_arg : N;
     constexpr int ES = FP8 ? 1 : 2, BK = 128 / ES;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void *__restrict__ Xv
         tile_m = blockIdx.x / tiles_n;
         tile_n = blockIdx.x - tile_m * tiles_n;
     }
-    const int m0 = tile_m * 256, n0 = tile_n * BN;
+    const int m0 = tile_m * 256, n0 = (SWIGLU ? col0 : 0) + tile_n * BN;
 
     // ---- DMA plan.  Group kinds: 0 = A rows 0-63 of both halves, 1 = B first column piece, 2 = B second column piece,
     //      3 = A rows 64-127.  A group = 16 pieces of 8 rows x 128 B; this wave moves pieces pi = i*8 + wave, i = 0, 1.
@@ -277,11 +278,16 @@ __device__ __forceinline__ void g8_wait_instrs(int n) {   // n = DMA wave instru
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <bool FP8, bool HAS_EPI>
+// SWIGLU: W = fused gate_up [2I, K]; the tile's 128 weight rows are 64 gate rows n0 .. and the 64 up rows I + n0 ..; wave wc
+// multiplies gate columns n0 + 16 wc .. + 16 and the matching up columns, C is [M, I] (N = 2I); col0 = first column of the launch.
+// Used for the columns that a whole number of 256-CU rounds of the 128-column SwiGLU tiles leaves over.
+template <bool FP8, bool HAS_EPI, bool SWIGLU = false>
 __global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict__ Xv, const void *__restrict__ Wv, half_t *C, int M, int N,
                                                           int K, const half_t *__restrict__ bias, const half_t *residual, int tiles_n,
                                                           const float *__restrict__ xscale, const float *__restrict__ wscale,
-                                                          int ldc_arg = 0, int group_m = 0) {
+                                                          int ldc_arg = 0, int group_m = 0, int col0 = 0) {
+    static_assert(!SWIGLU || !HAS_EPI, "SwiGLU form: no bias / residual");
+    const int half_n = N >> 1;
     const size_t ldc = ldc_arg ? ldc_arg : N;
     constexpr int ES = FP8 ? 1 : 2, BK = 128 / ES;
     constexpr unsigned SLOT_BYTES = 128 * 128;
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict
         tile_m = blockIdx.x / tiles_n;
         tile_n = blockIdx.x - tile_m * tiles_n;
     }
-    const int m0 = tile_m * 256, n0 = tile_n * 128;
+    const int m0 = tile_m * 256, n0 = SWIGLU ? col0 + tile_n * 64 : tile_n * 128;
 
     // DMA plan: kind 0 = B, 1 = A0, 2 = A1 (the group order inside a k-tile); this wave moves pieces pi = i*8 + wave (8 slot rows each)
     const size_t row_bytes = static_cast<size_t>(K) * ES;
@@ -317,7 +323,10 @@ __global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict
     for (int i = 0; i < 2; ++i) {
         const int pi = i * 8 + wave, row = pi * 8 + (lane >> 3), chunk = (lane & 7) ^ (row & 7);   // slot row of this lane
         ldst[i] = __builtin_amdgcn_readfirstlane(lds_addr + pi * 1024);
-        voff[0][i] = static_cast<unsigned>(static_cast<long>(min(n0 + row, N - 1) - n0) * static_cast<long>(row_bytes) + chunk * 16);
+        if constexpr (SWIGLU)   // slot rows 0-63: gate rows n0 + row; 64-127: up rows I + n0 + row - 64 (clamped inside their half)
+            voff[0][i] = static_cast<unsigned>((static_cast<long>(row >> 6) * half_n + min(n0 + (row & 63), half_n - 1) - n0) * static_cast<long>(row_bytes) + chunk * 16);
+        else
+            voff[0][i] = static_cast<unsigned>(static_cast<long>(min(n0 + row, N - 1) - n0) * static_cast<long>(row_bytes) + chunk * 16);
 #pragma unroll
         for (int a = 0; a < 2; ++a) {   // slot rows 0-63 -> A half 0, 64-127 -> A half 1; rows (row % 64) + 64 a of the half
             const int arow = (row >> 6) * 128 + (row & 63) + 64 * a;
@@ -340,9 +349,11 @@ __global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    const int wcol = wc * 32;
+    const int wcol = SWIGLU ? wc * 16 : wc * 32;
     const unsigned sw0 = static_cast<unsigned>(((FP8 ? 2 * q : q) ^ (r & 7)) << 4), sw1 = static_cast<unsigned>(((FP8 ? 2 * q + 1 : 4 + q) ^ (r & 7)) << 4);
-    const unsigned a_lane = (wr * 64 + r) * 128, b_lane = (wc * 32 + r) * 128;
+    // B fragment jj: plain -> slot row wc*32 + jj*16 + r; SwiGLU -> jj = 0 the gate row wc*16 + r, jj = 1 the up row 64 + wc*16 + r
+    const unsigned a_lane = (wr * 64 + r) * 128, b_lane = ((SWIGLU ? wc * 16 : wc * 32) + r) * 128;
+    constexpr unsigned B_STEP = SWIGLU ? 64 * 128 : 16 * 128;
     G8Frag<FP8> fa[4], fb[3][2];   // A piece; B fragments of k-tiles u % 3 = 0, 1, 2
     auto read_a = [&](unsigned slot) {
         const unsigned char *p = lds + slot * SLOT_BYTES + a_lane;
@@ -352,7 +363,7 @@ __global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict
     auto read_b = [&](unsigned slot, G8Frag<FP8> (&f)[2]) {
         const unsigned char *p = lds + slot * SLOT_BYTES + b_lane;
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) g8_read<FP8>(f[jj], p + jj * 2048, sw0, sw1);
+        for (int jj = 0; jj < 2; ++jj) g8_read<FP8>(f[jj], p + jj * B_STEP, sw0, sw1);
     };
     auto half_tile = [&](auto ih_, G8Frag<FP8> (&f)[2]) {
         constexpr int ih = decltype(ih_)::value;
@@ -427,7 +438,7 @@ __global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict
     if (u + 1 < KT) { phase(std::integral_constant<int, 2>{}, u + 1, std::false_type{}); phase(std::integral_constant<int, 3>{}, u + 1, std::false_type{}); }
     if (wr == 0) __builtin_amdgcn_s_barrier();
 
-    g256_store<FP8, HAS_EPI, 2, false>(acc, C, M, N, ldc, m0, n0, wr, wcol, r, q, bias, residual, xscale, wscale);
+    g256_store<FP8, HAS_EPI, 2, SWIGLU>(acc, C, M, N, ldc, m0, n0, wr, wcol, r, q, bias, residual, xscale, wscale);
 }
 
 }  // namespace llmie

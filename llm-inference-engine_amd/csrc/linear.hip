@@ -608,10 +608,39 @@ void gemm256_swiglu_launch(bool fp8, const void *x, const void *W, half_t *y, in
             return true;
         }();
         (void)attr8;
+        // Rounds of the 256 CUs, as gemm256_launch plans them: a partly filled last round of 128-column tiles (4096 tokens: 1376 tiles =
+        // 5.4 rounds) runs instead as 64-column tiles (gemm8p_n128_kernel's SwiGLU form, ~0.6 of a wide tile each) over the
+        // left-over columns, in a second launch -- when that is cheaper (not at 2048 tokens: 2.7 rounds become 2 + 2 x 0.6)
+        constexpr int cus = 256, ring_bytes = 9 * 128 * 128;
+        auto rounds = [&](int t) { return (t + cus - 1) / cus; };
+        const int inter = two_inter / 2, tiles = tm * tn, full = tiles / cus;
+        int a_tn = tn, b_tn = 0;
+        if (full >= 1 && tiles % cus != 0 && inter % 4 == 0) {
+            const int a = full * cus / tm;   // 128-column tiles that make whole rounds
+            if (a > 0 && a < tn) {
+                const int tnb = (inter - a * 128 + 63) / 64;
+                if (rounds(a * tm) + rounds(tm * tnb) * 0.6f < static_cast<float>(rounds(tiles))) {
+                    a_tn = a;
+                    b_tn = tnb;
+                }
+            }
+        }
         if (fp8)
-            gemm8p_kernel<true, false, true><<<tm * tn, 512, lds_bytes, st>>>(x, W, y, M, two_inter, K, nullptr, nullptr, tn, xscale, wscale, 0, g256_group_m());
+            gemm8p_kernel<true, false, true><<<tm * a_tn, 512, lds_bytes, st>>>(x, W, y, M, two_inter, K, nullptr, nullptr, a_tn, xscale, wscale, 0, g256_group_m(), 0);
         else
-            gemm8p_kernel<false, false, true><<<tm * tn, 512, lds_bytes, st>>>(x, W, y, M, two_inter, K, nullptr, nullptr, tn, nullptr, nullptr, 0, g256_group_m());
+            gemm8p_kernel<false, false, true><<<tm * a_tn, 512, lds_bytes, st>>>(x, W, y, M, two_inter, K, nullptr, nullptr, a_tn, nullptr, nullptr, 0, g256_group_m(), 0);
+        if (b_tn) {
+            static const bool attrn = [] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm8p_n128_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ring_bytes);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm8p_n128_kernel<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ring_bytes);
+                return true;
+            }();
+            (void)attrn;
+            if (fp8)
+                gemm8p_n128_kernel<true, false, true><<<tm * b_tn, 512, ring_bytes, st>>>(x, W, y, M, two_inter, K, nullptr, nullptr, b_tn, xscale, wscale, 0, g256_group_m(), a_tn * 128);
+            else
+                gemm8p_n128_kernel<false, false, true><<<tm * b_tn, 512, ring_bytes, st>>>(x, W, y, M, two_inter, K, nullptr, nullptr, b_tn, nullptr, nullptr, 0, g256_group_m(), a_tn * 128);
+        }
         return;
     }
     if (fp8)

@@ -282,7 +282,8 @@ def test_linear_eight_phase_schedule_race_screen(llmie, M, K, N):
         assert torch.equal(y, y0), "launch %d differs from the first in %d elements" % (it, (y != y0).sum().item())
 
 
-@pytest.mark.parametrize("M,K,I", [(4096, 128, 3072), (4000, 192, 3100), (300, 256, 344)])
+@pytest.mark.parametrize("M,K,I", [(4096, 128, 3072), (4000, 192, 3100), (300, 256, 344),
+                                   (4000, 192, 3000), (1024, 320, 11008)])   # two-launch plans: 128-column tiles for whole rounds + 64-column tiles (ragged last tile)
 def test_linear_swiglu_large_m(llmie, M, K, I):
     """ffn.cpp:105-122 in one launch at prefill sizes: the 256-token tile multiplies 128 gate and the matching 128 up rows
     and forms silu(gate) * up in registers (gemm256.cuh SWIGLU form); the small case falls back to ... an error unless a
