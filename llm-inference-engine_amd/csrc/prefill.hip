@@ -153,13 +153,6 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
     for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const half8_t *>(qptr + 32 * s + 8 * q);
     const int qpos = history + qrow_c;  // keys t <= qpos are visible
 
-    // element offset of key row t of this (sequence, kv head): dense slab, or the 128-token page of the block table (a 64-key
-    // tile never crosses a page; the lookup happens where the tile is FETCHED, two iterations before it is used)
-    auto row_off = [&](int t) -> size_t {
-        if (table)
-            return layer_off + ((static_cast<size_t>(table[static_cast<size_t>(b) * max_pages + t / 128]) * kv_head_num + g) * 128 + t % 128) * HS;
-        return layer_off + ((static_cast<size_t>(b) * kv_head_num + g) * max_seq_len + t) * HS;
-    };
     const half_t *kc = static_cast<const half_t *>(k_cache), *vc = static_cast<const half_t *>(v_cache);
     const uint8_t *kc8 = static_cast<const uint8_t *>(k_cache), *vc8 = static_cast<const uint8_t *>(v_cache);
     (void)kc; (void)vc; (void)kc8; (void)vc8;
@@ -175,16 +168,22 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
     uint2 kreg8[NCH], vreg8[NCH];
     (void)kreg; (void)vreg; (void)kreg8; (void)vreg8;
     auto fetch_tile = [&](int t0) {  // global -> registers
+        // One page lookup per TILE, wave-uniform (a scalar load): the 64 keys of a tile lie in one 128-token page, and so does the
+        // clamp target ctx - 1 of a tile's rows past the context (t0 <= ctx - 1 < t0 + 64).  Looked up per chunk through
+        // row_off(), the table entry was a dependent VECTOR load in front of every K / V load with a vmcnt(0) between them.
+        const size_t tile_base = table ? layer_off + (static_cast<size_t>(__builtin_amdgcn_readfirstlane(table[static_cast<size_t>(b) * max_pages + t0 / 128])) * kv_head_num + g) * 128 * HS
+                                       : layer_off + (static_cast<size_t>(b) * kv_head_num + g) * max_seq_len * HS;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int id = tid + NTHR * i, row = id >> 4, ch = id & 15;
             const int t = min(t0 + row, ctx - 1);
+            const size_t off = tile_base + static_cast<size_t>(table ? t % 128 : t) * HS;
             if constexpr (KV8) {
-                kreg8[i] = *reinterpret_cast<const uint2 *>(kc8 + row_off(t) + ch * 8);
-                vreg8[i] = *reinterpret_cast<const uint2 *>(vc8 + row_off(t) + ch * 8);
+                kreg8[i] = *reinterpret_cast<const uint2 *>(kc8 + off + ch * 8);
+                vreg8[i] = *reinterpret_cast<const uint2 *>(vc8 + off + ch * 8);
             } else {
-                kreg[i] = *reinterpret_cast<const half8_t *>(kc + row_off(t) + ch * 8);
-                vreg[i] = *reinterpret_cast<const half8_t *>(vc + row_off(t) + ch * 8);
+                kreg[i] = *reinterpret_cast<const half8_t *>(kc + off + ch * 8);
+                vreg[i] = *reinterpret_cast<const half8_t *>(vc + off + ch * 8);
             }
         }
     };
