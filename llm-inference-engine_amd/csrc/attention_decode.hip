@@ -119,33 +119,43 @@ __device__ __forceinline__ size_t attn_out_index(int x32, int b, int k, int widt
 // Merge of the per-split (m, l, o[d]) partials of one (batch, head) for output dim d: 16 splits per round,
 // every load of a round issued before the first use.  Shared by the stand-alone merge kernel and by the
 // in-kernel merge of the last-arriving workgroup, so both give bit-identical results.
+// one round of the merge: the 16 (m, l, o[d]) triples of splits s0 .. s0 + 15 (those >= nsplits are ignored) enter (M, L, o)
+__device__ __forceinline__ void merge_round(const float (&ms)[16], const float (&ls)[16], const float (&os)[16], int s0, int nsplits,
+                                            float &M, float &L, float &o) {
+    float Mc = M;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (s0 + i < nsplits) Mc = fmaxf(Mc, ms[i]);
+    const float rescale = (M == -INFINITY) ? 0.f : __expf(M - Mc);
+    L *= rescale;
+    o *= rescale;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (s0 + i < nsplits) {
+            const float f = __expf(ms[i] - Mc);
+            L = fmaf(f, ls[i], L);
+            o = fmaf(f, os[i], o);
+        }
+    M = Mc;
+}
+// loads of one round; slots are clamped to `last` (nsplits - 1, or the last slot of the buffer when the loads are issued before
+// the number of splits is known: what a clamped-away slot holds is never used)
+__device__ __forceinline__ void merge_load(const float *__restrict__ p, int s0, int last, size_t stride, int d, float (&ms)[16],
+                                           float (&ls)[16], float (&os)[16]) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int s = min(s0 + i, last);
+        ms[i] = p[s * stride];
+        ls[i] = p[s * stride + 1];
+        os[i] = p[s * stride + 2 + d];
+    }
+}
 __device__ __forceinline__ float merge_splits(const float *__restrict__ p, int nsplits, size_t stride, int d) {
-    auto ld = [&](const float *q) -> float { return *q; };
     float M = -INFINITY, L = 0.f, o = 0.f;
     for (int s0 = 0; s0 < nsplits; s0 += 16) {
         float ms[16], ls[16], os[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int s = min(s0 + i, nsplits - 1);
-            ms[i] = ld(p + s * stride);
-            ls[i] = ld(p + s * stride + 1);
-            os[i] = ld(p + s * stride + 2 + d);
-        }
-        float Mc = M;
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (s0 + i < nsplits) Mc = fmaxf(Mc, ms[i]);
-        const float rescale = (M == -INFINITY) ? 0.f : __expf(M - Mc);
-        L *= rescale;
-        o *= rescale;
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (s0 + i < nsplits) {
-                const float f = __expf(ms[i] - Mc);
-                L = fmaf(f, ls[i], L);
-                o = fmaf(f, os[i], o);
-            }
-        M = Mc;
+        merge_load(p, s0, nsplits - 1, stride, d, ms, ls, os);
+        merge_round(ms, ls, os, s0, nsplits, M, L, o);
     }
     return o / (L + 1e-6f);
 }
@@ -604,12 +614,27 @@ __global__ __launch_bounds__(256) void decode_attn_combine_kernel(const float *_
                                                                   const int32_t *__restrict__ step_dev,
                                                                   int max_splits, int step_stride, int max_seq_len, int out_x32) {
     const int h = blockIdx.x, b = blockIdx.y;
+    const size_t stride = static_cast<size_t>(head_size) + 2;
+    const float *p = part + (static_cast<size_t>(b) * head_num + h) * max_splits * stride;
+    // The first round's loads do not wait for the device-resident position: they go out beside its load, clamped to the buffer
+    // (a slot past the live splits holds an older step's values, which merge_round never looks at) -- one L2 round trip less in
+    // a kernel that is three dependent round trips and a launch.  Same arithmetic as merge_splits: bit-identical.
+    int d = threadIdx.x;
+    float ms[16], ls[16], os[16];
+    merge_load(p, 0, max_splits - 1, stride, min(d, head_size - 1), ms, ls, os);
     const int step = seq_step(step_dev, step_arg, step_stride, b, max_seq_len);
     const int nsplits = (step + chunk - 1) / chunk;
     if (nsplits <= 1) return;  // the split kernel already wrote the final output (or: invalid position)
-    const size_t stride = static_cast<size_t>(head_size) + 2;
-    const float *p = part + (static_cast<size_t>(b) * head_num + h) * max_splits * stride;
-    for (int d = threadIdx.x; d < head_size; d += blockDim.x)
+    if (d < head_size) {
+        float M = -INFINITY, L = 0.f, o = 0.f;
+        merge_round(ms, ls, os, 0, nsplits, M, L, o);
+        for (int s0 = 16; s0 < nsplits; s0 += 16) {
+            merge_load(p, s0, nsplits - 1, stride, d, ms, ls, os);
+            merge_round(ms, ls, os, s0, nsplits, M, L, o);
+        }
+        out[attn_out_index(out_x32, b, h * head_size + d, head_num * head_size)] = from_f32<T>(o / (L + 1e-6f));
+    }
+    for (d += blockDim.x; d < head_size; d += blockDim.x)   // head sizes above the block size
         out[attn_out_index(out_x32, b, h * head_size + d, head_num * head_size)] = from_f32<T>(merge_splits(p, nsplits, stride, d));
 }
 
