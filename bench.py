@@ -539,7 +539,7 @@ def main():
     gu_bytes = 2 * I * H * 2  # fused gate_up matrix streamed once per launch (180.4 MB)
     gu_ms, gu_n = prof["gate_up_swiglu"]
     gu_us = gu_ms / gu_n * 1e3
-    roofline = roofline_block("gemv_ksplit_kernel<M=%d,RPW=8,XC=2,fp16> (RMSNorm + gate/up projection + SwiGLU)" % B, "hbm", gu_bytes,
+    roofline = roofline_block("gemv_ksplit_kernel<M=%d,RPW=4,XC=2,fp16> (RMSNorm + gate/up projection + SwiGLU)" % B, "hbm", gu_bytes,
                               gu_us, gu_n, HBM_PEAK_GBS, "GB/s", "decode_f16_b1_ctx2048" if (B == 1 and S == 2048) else "")
     step_bytes = decode_bytes_per_step(cfg, B, S)
     whole = dict(algorithmic_bytes_per_step=step_bytes,

@@ -13,5 +13,5 @@ python $S stats $P/kt_pf profiles/r02_prefill_kernel_stats.csv "rocprofv3 --kern
 python $S sq $P/sq_pf profiles/r02_gemm256_pmc.csv "$SQ -- python3 bench.py --only prefill:f16:1:2048  (tools/profile_r02.sh)" gemm8p gemm256
 python $S sq $P/sq_pf profiles/r02_flash_pmc.csv "$SQ -- python3 bench.py --only prefill:f16:1:2048  (tools/profile_r02.sh)" prefill_flash
 python $S roofline profiles/r02_rocprof_roofline.json decode_int8_b32_ctx128 $P/kt_i8 "pk_mfma_kernel<2, 8, 1, 1>" 131072 profiles/r02_int8_b32_kernel_stats.csv /tmp/r02_i8_gu.json
-python $S roofline profiles/r02_rocprof_roofline.json decode_f16_b1_ctx2048 $P/kt_f16 "gemv_ksplit_kernel<1, 8, 2, 16" 176128 profiles/r02_decode_kernel_stats.csv profiles/r01_pmc_traffic.json
+python $S roofline profiles/r02_rocprof_roofline.json decode_f16_b1_ctx2048 $P/kt_f16 "gemv_ksplit_kernel<1, 4, 2, 16" 128256 profiles/r02_decode_kernel_stats.csv profiles/r01_pmc_traffic.json
 python $S roofline profiles/r02_rocprof_roofline.json prefill_f16_b1_s2048 $P/kt_pf "gemm8p_kernelILb0ELb0ELb1E" 352256 profiles/r02_prefill_kernel_stats.csv
