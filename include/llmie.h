@@ -35,7 +35,13 @@
 extern "C" {
 #endif
 
-#define LLMIE_ABI_VERSION 1
+/* ABI history (llmie_abi_version() returns the library's; a consumer compares it with the header it was built against):
+ *   1  round 1.
+ *   2  llmie_linear, llmie_linear_swiglu, llmie_linear_w8a16, llmie_linear_w4a16 gained (workspace, workspace_bytes) in front
+ *      of the stream argument and llmie_linear_fp8_workspace_bytes gained N; w8a16 with M > 64 / w4a16 with M > 8 need a
+ *      workspace (NULL -> LLMIE_ERR_UNSUPPORTED).  A version-1 consumer would pass its stream where the slab pointer goes.
+ *   3  round 3: additions only are listed at the entries they concern (int8 / int4 weight-only prefill, decoder config flags). */
+#define LLMIE_ABI_VERSION 3
 
 typedef enum { LLMIE_F32 = 0, LLMIE_F16 = 1 } llmie_dtype;
 

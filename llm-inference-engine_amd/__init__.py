@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libllmie.so")
 F32, F16 = 0, 1
 W_F16, W_INT8, W_INT4, W_FP8, W_F32 = 0, 1, 2, 3, 4
 KV_NATIVE, KV_FP8 = 0, 1
+ABI_VERSION = 3  # LLMIE_ABI_VERSION of include/llmie.h this binding mirrors
 
 _lib = None
 
@@ -133,8 +134,9 @@ def lib():
             fn = getattr(l, name)  # AttributeError if the ABI lost a symbol
             fn.argtypes = args
             fn.restype = _RESTYPES.get(name, C.c_int)
-        if l.llmie_abi_version() != 1:
-            raise LlmieError("libllmie.so ABI version mismatch")
+        if l.llmie_abi_version() != ABI_VERSION:
+            raise LlmieError("libllmie.so ABI version %d, this binding was written against %d (include/llmie.h)"
+                             % (l.llmie_abi_version(), ABI_VERSION))
         _lib = l
     return _lib
 

@@ -341,6 +341,11 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
             x[e] = x[e] * rc[e] + partner * rs[e];
         }
     };
+    // e4m3 cache: the scale operand of v_cvt_scalef32_pk_f16_fp8 is E8M0 (only the exponent bits of the float are used), so the
+    // conversion gets the power-of-two part of k_scale and q carries the mantissa remainder (in [1, 2)) in fp32
+    const float k_p2 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, k_scale) & 0x7f800000u);
+    const float k_q = FP8KV ? k_scale / k_p2 : k_scale;
+    (void)k_p2;
     float qf[REP][N];
 #pragma unroll
     for (int r = 0; r < REP; ++r) {
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
 #pragma unroll
         for (int e = 0; e < N; ++e) {
             f[e] += qkv_bias ? to_f32(qbias[r][e]) : 0.f;
-            qf[r][e] = f[e] * (FP8KV ? scale : scale * k_scale);  // the cache holds k / k_scale (fp8: applied by the conversion)
+            qf[r][e] = f[e] * (scale * k_q);  // the cache holds k / k_scale (fp8: the conversion applies the power-of-two part)
         }
     }
     // e4m3 cache: K.q on packed fp16 -- v_cvt_scalef32_pk_f16_fp8 turns two cache bytes into (k0, k1) * k_scale in one instruction
@@ -450,8 +455,8 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
             const uint4_t kw = __builtin_bit_cast(uint4_t, kv[i]);
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                kh[2 * w] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(kw[w]), k_scale, false);
-                kh[2 * w + 1] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(kw[w]), k_scale, true);
+                kh[2 * w] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(kw[w]), k_p2, false);
+                kh[2 * w + 1] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(kw[w]), k_p2, true);
             }
         } else {
             kv_to_f32<KT, N>(kv[i], kf);

@@ -142,7 +142,13 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int heads = head_num + 2 * kv_head_num;
-    const float scale = rsqrtf(static_cast<float>(HS));
+    // e4m3 cache: the scale operand of v_cvt_scalef32_pk_f16_fp8 is E8M0 -- only the exponent bits of the float are used -- so the
+    // conversion applies the power-of-two part of each cache scale and the mantissa remainder (in [1, 2)) is applied in fp32:
+    // K's in the softmax scale, V's on the output row
+    const float k_p2 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, k_scale) & 0x7f800000u);
+    const float v_p2 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v_scale) & 0x7f800000u);
+    const float k_rem = KV8 ? k_scale / k_p2 : 1.f, v_rem = KV8 ? v_scale / v_p2 : 1.f;
+    const float scale = rsqrtf(static_cast<float>(HS)) * k_rem;
 
     // this lane's query row (clamped for the tail tile; its results are not stored)
     const int qrow = q0 + wave * 16 + r;
@@ -195,14 +201,14 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
             if constexpr (KV8) {
                 // 8 e4m3 bytes -> 8 halves (x scale): the tiles in LDS are fp16 either way
                 const uint2 kb = kreg8[i], vb = vreg8[i];
-                const half2_t k0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(kb.x), k_scale, false);
-                const half2_t k1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(kb.x), k_scale, true);
-                const half2_t k2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(kb.y), k_scale, false);
-                const half2_t k3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(kb.y), k_scale, true);
-                const half2_t v0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(vb.x), v_scale, false);
-                const half2_t v1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(vb.x), v_scale, true);
-                const half2_t v2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(vb.y), v_scale, false);
-                const half2_t v3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(vb.y), v_scale, true);
+                const half2_t k0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(kb.x), k_p2, false);
+                const half2_t k1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(kb.x), k_p2, true);
+                const half2_t k2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(kb.y), k_p2, false);
+                const half2_t k3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(kb.y), k_p2, true);
+                const half2_t v0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(vb.x), v_p2, false);
+                const half2_t v1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(vb.x), v_p2, true);
+                const half2_t v2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(vb.y), v_p2, false);
+                const half2_t v3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(static_cast<int>(vb.y), v_p2, true);
                 kvv = half8_t{k0[0], k0[1], k1[0], k1[1], k2[0], k2[1], k3[0], k3[1]};
                 vvv = half8_t{v0[0], v0[1], v1[0], v1[1], v2[0], v2[1], v3[0], v3[1]};
             } else {
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
     if (qrow < len) {
-        const float inv = 1.0f / (l_run + 1e-6f);  // the reference's denominator epsilon (scale_and_mask_and_softmax.cu:118)
+        const float inv = v_rem / (l_run + 1e-6f);  // the reference's denominator epsilon (scale_and_mask_and_softmax.cu:118)
         half_t *optr = out + (static_cast<size_t>(cum[b] + qrow) * head_num + h) * HS;
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) {

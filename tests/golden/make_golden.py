@@ -138,6 +138,37 @@ def main():
         "q_lens": ql.tolist(), "k_lens": kl.tolist(),
         "mask_sha256_uint8": sha(m), "ones": int(m.sum()),
     }
+    # ---- recipes the reference's tests hold whose answers follow by hand (round 3; VERDICT r2 "missing" item 5) ----
+    # tests/unit_tests/test_add_residual_and_rmsnorm.cu:60-80: decoder_out = 1, residual = 0, bias = 0, gamma = 1, eps = 0.5,
+    # [2048, 128] -> sum = 1 everywhere, mean square 1, every output 1/sqrt(1 + 0.5); the new residual is the sum (= 1)
+    g["fused_norm_ones"] = {
+        "source": "tests/unit_tests/test_add_residual_and_rmsnorm.cu:60-80",
+        "tokens": 2048, "hidden": 128, "eps": 0.5, "out_fill": 1.0, "residual_fill": 0.0, "bias_fill": 0.0, "gamma_fill": 1.0,
+        "expected": float(1.0 / np.sqrt(np.float64(1.5))), "expected_residual": 1.0, "tol": 1e-3,
+    }
+    # tests/unit_tests/test_scale_and_mask_and_softmax.cu:29-35,88-95: qk[i] = i % 8 over [1, 2, 8, 8] (k_length 8, so every row
+    # is 0..7), mask all ones, scale = rsqrt(head_size 4) = 0.5; the kernel's denominator carries +1e-6
+    # (scale_and_mask_and_softmax.cu:118) -> every row = exp(0.5 j - 3.5) / (sum + 1e-6)
+    e = np.exp(0.5 * np.arange(8, dtype=np.float64) - 3.5)
+    g["softmax_mod8"] = {
+        "source": "tests/unit_tests/test_scale_and_mask_and_softmax.cu:29-35,88-95",
+        "shape": [1, 2, 8, 8], "qk": "i % 8 over the flat buffer", "mask": "ones [1, 8, 8]", "scale": 0.5,
+        "row": (e / (e.sum() + 1e-6)).tolist(), "tol": 1e-5,
+    }
+    # tests/unit_tests/test_concat_past_kv.cu:16-62: k/v source all ones [1, 2, 16, 8], history 1, query length 16, cache
+    # [1, 1, 2, 32, 8]: rows 1..16 of both kv heads become 1, rows 0 and 17..31 are not written
+    g["concat_kv_ones"] = {
+        "source": "tests/unit_tests/test_concat_past_kv.cu:16-62",
+        "batch": 1, "kv_head_num": 2, "max_q_len": 16, "max_seq_len": 32, "head_size": 8, "cur_query_length": [16],
+        "history_length": [1], "layer": 0, "src_fill": 1.0, "written_rows": [1, 16],
+    }
+    # tests/unit_tests/test_repeat_kv.cu:16-58: cache[i] = i over [2, 1, 2, 4, 2], ctx_len 2, layer 0, head_num = kv_head_num
+    # = 2, max_k_len 2 -> out[0, h, t, d] = cache[0, 0, h, t, d] = 8 h + 2 t + d
+    g["repeat_kv_ramp"] = {
+        "source": "tests/unit_tests/test_repeat_kv.cu:16-58",
+        "cache_shape": [2, 1, 2, 4, 2], "ctx_len": [2], "layer": 0, "head_num": 2, "max_k_len": 2,
+        "expected": [0.0, 1.0, 2.0, 3.0, 8.0, 9.0, 10.0, 11.0],
+    }
     with open(os.path.join(HERE, "known_answers.json"), "w") as f:
         json.dump(g, f, indent=1, sort_keys=True)
     print("wrote", os.path.join(HERE, "known_answers.json"))

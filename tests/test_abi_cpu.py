@@ -30,8 +30,9 @@ def test_every_declared_symbol_is_exported(lib, llmie):
     assert sorted(llmie.EXPORTS) == names
 
 
-def test_version_and_arch(lib):
-    assert lib.llmie_abi_version() == 1
+def test_version_and_arch(lib, llmie):
+    assert lib.llmie_abi_version() == 3 == llmie.ABI_VERSION
+    assert "#define LLMIE_ABI_VERSION 3" in open(os.path.join(ROOT, "include", "llmie.h")).read()
     assert lib.llmie_target_arch() == b"gfx950"
 
 

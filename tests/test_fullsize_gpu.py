@@ -75,8 +75,13 @@ def test_graph_replay_equals_eager(llmie, full):
     step_dev.fill_(301)
     g.replay()
     torch.cuda.synchronize()
-    ref = dec.forward(x, torch.empty_like(x), k_eager.clone(), vc.clone(), 301)
-    assert torch.isfinite(out.float()).all() and out.shape == ref.shape
+    # same kernels, same inputs (the cache as the step-300 launch left it), the step passed by value this time: bit-identical,
+    # and the token row of step 301 landed in the graph's cache
+    k_ref, v_ref = k_eager.clone(), vc.clone()
+    ref = dec.forward(x, torch.empty_like(x), k_ref, v_ref, 301)
+    assert torch.isfinite(out.float()).all() and torch.equal(out, ref)
+    assert torch.equal(kc, k_ref) and torch.equal(vc, v_ref)
+    assert not torch.equal(kc[:, :, :, 300], k_eager[:, :, :, 300])
     dec.close()
 
 
@@ -108,7 +113,16 @@ def test_prefill_then_decode_consistency_32_layers(llmie, full):
     a, b = last.float(), full_out[n:n + 1].float()
     rel = (a - b).norm() / b.norm()
     assert rel.item() < 2e-2, rel.item()  # 32 layers of fp16 activations through two different kernel families
-    assert (k1.float() - k2.float()).abs().max().item() < 0.25
+    # the caches of the two routes: rows 0..n-1 come from two prefills of different row counts (other tile plans), row n from
+    # the prefill in one and the decode kernels in the other; every layer's K / V rows are fp16 roundings of projections of
+    # hidden states that agree to the fp16 decoder tolerance
+    for a_c, b_c, nm in ((k1, k2, "k"), (v1, v2, "v")):
+        af, bf = a_c[:, :, :, :n + 1].float(), b_c[:, :, :, :n + 1].float()
+        d = (af - bf).abs()
+        relf = ((af - bf).flatten(1).norm(dim=1) / bf.flatten(1).norm(dim=1)).max().item()
+        print("%s cache: max abs diff %.4g, worst per-layer rel Frobenius %.4g" % (nm, d.max().item(), relf))
+        assert relf < 1e-2, (nm, relf)
+        assert (d <= 2e-2 + 2e-2 * bf.abs()).all(), (nm, d.max().item())
     dec.close()
 
 

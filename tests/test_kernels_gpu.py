@@ -159,6 +159,18 @@ def test_fused_add_bias_residual_rmsnorm(llmie, dtype, T, H, bias, resid):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_fused_norm_reference_recipe(llmie, golden, dtype):
+    g = golden["fused_norm_ones"]  # test_add_residual_and_rmsnorm.cu:60-80: out 1, residual 0, bias 0, gamma 1, eps 0.5
+    T, H = g["tokens"], g["hidden"]
+    od = torch.full((T, H), g["out_fill"], dtype=dtype, device=DEV)
+    rd = torch.full((T, H), g["residual_fill"], dtype=dtype, device=DEV)
+    llmie.fused_add_bias_residual_rmsnorm(rd, od, torch.full((H,), g["bias_fill"], dtype=dtype, device=DEV),
+                                          torch.full((H,), g["gamma_fill"], dtype=dtype, device=DEV), g["eps"])
+    assert np.abs(host(od) - g["expected"]).max() <= (1e-6 if dtype == torch.float32 else 5e-4)  # the reference's bar: 1e-3
+    assert (host(rd) == g["expected_residual"]).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("T,H", [(16, 4096), (1, 128), (3, 33)])
 def test_add_residual(llmie, dtype, T, H):
     # test_add_residual.cu: T=16, H=4096, both (i%2)+1  -> exact
@@ -393,7 +405,34 @@ def test_concat_and_repeat_kv(llmie, dtype):
         assert np.array_equal(host(dst), orc.repeat_kv(exp, ctx, layer, nh, max_k, fill=-3.0))
 
 
+def test_concat_and_repeat_kv_reference_recipes(llmie, golden):
+    g = golden["concat_kv_ones"]  # test_concat_past_kv.cu: ones, history 1, 16 new rows into a 32-row cache
+    src = torch.full((g["batch"], g["kv_head_num"], g["max_q_len"], g["head_size"]), g["src_fill"], device=DEV)
+    cache = torch.full((1, g["batch"], g["kv_head_num"], g["max_seq_len"], g["head_size"]), -7.0, device=DEV)
+    llmie.concat_kv(src, cache, dev(np.array(g["cur_query_length"], np.int32)), dev(np.array(g["history_length"], np.int32)),
+                    g["layer"])
+    c = host(cache)
+    lo, hi = g["written_rows"]
+    assert (c[0, :, :, lo:hi + 1] == 1.0).all() and (c[0, :, :, :lo] == -7.0).all() and (c[0, :, :, hi + 1:] == -7.0).all()
+    g = golden["repeat_kv_ramp"]  # test_repeat_kv.cu: cache[i] = i, ctx 2, layer 0
+    ramp = torch.arange(int(np.prod(g["cache_shape"])), dtype=torch.float32, device=DEV).reshape(g["cache_shape"])
+    dst = torch.zeros((1, g["head_num"], g["max_k_len"], g["cache_shape"][-1]), device=DEV)
+    llmie.repeat_kv(ramp, dst, dev(np.array(g["ctx_len"], np.int32)), g["layer"])
+    assert host(dst).reshape(-1).tolist() == g["expected"]
+
+
 # --------------------------------------------------------------------------- softmax / transpose / swiglu
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_scale_mask_softmax_reference_recipe(llmie, golden, dtype):
+    g = golden["softmax_mod8"]  # test_scale_and_mask_and_softmax.cu: qk = i % 8, mask ones, scale 0.5
+    bs, nh, ql, kl = g["shape"]
+    qk = (torch.arange(bs * nh * ql * kl, device=DEV) % 8).to(dtype).reshape(bs, nh, ql, kl)
+    out = torch.empty_like(qk)
+    llmie.scale_mask_softmax(qk, torch.ones((bs, ql, kl), dtype=dtype, device=DEV), out, g["scale"])
+    exp = np.broadcast_to(np.array(g["row"], np.float32), (bs, nh, ql, kl))
+    assert np.abs(host(out) - exp).max() <= (g["tol"] if dtype == torch.float32 else 5e-4)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("bs,nh,ql,kl", [(1, 2, 8, 8), (2, 4, 32, 32), (1, 3, 5, 300), (1, 2, 3, 2048), (1, 1, 2, 5000)])
 def test_scale_mask_softmax(llmie, dtype, bs, nh, ql, kl):

@@ -11,6 +11,9 @@ import oracle as orc
 pytestmark = pytest.mark.gpu
 DEV, F16 = "cuda", torch.float16
 KS, VS = 1.0 / 32, 1.0 / 16
+# non-power-of-two scales: the e4m3 conversion instruction takes an E8M0 scale operand (exponent bits only), so the kernels split
+# a scale into its power-of-two part (conversion) and the mantissa remainder (fp32); ADVICE round 2
+KS_NP2, VS_NP2 = 0.037, 0.021
 
 
 def _h(a):
@@ -48,7 +51,7 @@ def _layers(rng, nh, kvh, hs, I, L):
             for _ in range(L)]
 
 
-def _engine(llmie, layers, nh, kvh, hs, I, max_seq, max_batch, kv_fmt):
+def _engine(llmie, layers, nh, kvh, hs, I, max_seq, max_batch, kv_fmt, KS=KS, VS=VS):
     d = lambda a: torch.from_numpy(a).to(DEV).to(F16)
     eng = [dict(attn_norm=d(w["attn_norm"]), ffn_norm=d(w["ffn_norm"]), qkv=dict(data=d(w["qkv"])), o=dict(data=d(w["o"])),
                 gate_up=dict(data=d(w["gate_up"])), down=dict(data=d(w["down"]))) for w in layers]
@@ -62,11 +65,12 @@ def _engine(llmie, layers, nh, kvh, hs, I, max_seq, max_batch, kv_fmt):
     ("7Bgeom_b1", 32, 32, 128, 11008, 1, 1, 320, 300), ("7Bgeom_b4_L2", 32, 32, 128, 11008, 2, 4, 320, 300),
     ("gqa4_b2", 16, 4, 128, 1024, 2, 2, 600, 530), ("hs64_b3", 8, 8, 64, 768, 1, 3, 64, 33),
     ("batch20_splitk", 32, 32, 128, 11008, 2, 20, 288, 260)])
-def test_decode_with_fp8_kv_cache(llmie, name, nh, kvh, hs, I, L, bs, max_seq, step):
+@pytest.mark.parametrize("KS,VS", [(KS, VS), (KS_NP2, VS_NP2)], ids=["pow2", "np2"])
+def test_decode_with_fp8_kv_cache(llmie, name, nh, kvh, hs, I, L, bs, max_seq, step, KS, VS):
     rng = np.random.default_rng(61)
     H = nh * hs
     layers = _layers(rng, nh, kvh, hs, I, L)
-    dec = _engine(llmie, layers, nh, kvh, hs, I, max_seq, bs, llmie.KV_FP8)
+    dec = _engine(llmie, layers, nh, kvh, hs, I, max_seq, bs, llmie.KV_FP8, KS, VS)
     x = _h(rng.standard_normal((bs, H)).astype(np.float32))
     kraw = rng.standard_normal((L, bs, kvh, max_seq, hs)).astype(np.float32) * 0.7
     vraw = rng.standard_normal((L, bs, kvh, max_seq, hs)).astype(np.float32) * 0.7
@@ -93,12 +97,13 @@ def test_decode_with_fp8_kv_cache(llmie, name, nh, kvh, hs, I, L, bs, max_seq, s
     dec.close()
 
 
-def test_prefill_and_decode_agree_on_fp8_kv_cache(llmie):
+@pytest.mark.parametrize("KS,VS", [(KS, VS), (KS_NP2, VS_NP2)], ids=["pow2", "np2"])
+def test_prefill_and_decode_agree_on_fp8_kv_cache(llmie, KS, VS):
     rng = np.random.default_rng(62)
     nh, hs, I, L, max_seq, n = 8, 128, 1536, 2, 256, 150
     H = nh * hs
     layers = _layers(rng, nh, nh, hs, I, L)
-    d8 = _engine(llmie, layers, nh, nh, hs, I, max_seq, 1, llmie.KV_FP8)
+    d8 = _engine(llmie, layers, nh, nh, hs, I, max_seq, 1, llmie.KV_FP8, KS, VS)
     d16 = _engine(llmie, layers, nh, nh, hs, I, max_seq, 1, llmie.KV_NATIVE)
     xs = torch.from_numpy(_h(rng.standard_normal((n + 1, H)).astype(np.float32))).to(DEV).to(F16)
     z8 = lambda: torch.zeros((L, 1, nh, max_seq, hs), dtype=torch.uint8, device=DEV)

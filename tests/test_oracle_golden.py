@@ -123,3 +123,38 @@ def test_causal_mask_rand(golden):
     assert set(np.unique(m).tolist()) <= {0.0, 1.0}
     assert _sha(m.astype(np.uint8)) == g["mask_sha256_uint8"]
     assert int(m.sum()) == g["ones"]
+
+
+def test_fused_norm_ones(golden):
+    g = golden["fused_norm_ones"]  # pins a5 (fused add-bias-residual-RMSNorm)
+    T, H = g["tokens"], g["hidden"]
+    y, r = orc.fused_add_bias_residual_rmsnorm(np.full((T, H), g["residual_fill"], np.float32), np.full((T, H), g["out_fill"], np.float32),
+                                               np.full(H, g["bias_fill"], np.float32), np.full(H, g["gamma_fill"], np.float32), g["eps"])
+    assert np.abs(y - g["expected"]).max() <= 1e-6 and abs(g["expected"] - 0.8164966) < 1e-7
+    assert (r == g["expected_residual"]).all()
+
+
+def test_softmax_mod8(golden):
+    g = golden["softmax_mod8"]  # pins a14 (scale-mask-softmax)
+    bs, nh, ql, kl = g["shape"]
+    qk = (np.arange(bs * nh * ql * kl) % 8).astype(np.float32).reshape(bs, nh, ql, kl)
+    y = orc.scale_mask_softmax(qk, np.ones((bs, ql, kl), np.float32), g["scale"])
+    assert np.abs(y - np.array(g["row"], np.float64)).max() <= g["tol"]
+    assert abs(sum(g["row"]) - 1.0) < 2e-6
+
+
+def test_concat_kv_ones(golden):
+    g = golden["concat_kv_ones"]
+    src = np.full((g["batch"], g["kv_head_num"], g["max_q_len"], g["head_size"]), g["src_fill"], np.float32)
+    cache = np.full((1, g["batch"], g["kv_head_num"], g["max_seq_len"], g["head_size"]), -7.0, np.float32)
+    orc.concat_kv(src, cache, g["cur_query_length"], g["history_length"], g["layer"])
+    lo, hi = g["written_rows"]
+    assert (cache[0, :, :, lo:hi + 1] == 1.0).all()
+    assert (cache[0, :, :, :lo] == -7.0).all() and (cache[0, :, :, hi + 1:] == -7.0).all()
+
+
+def test_repeat_kv_ramp(golden):
+    g = golden["repeat_kv_ramp"]
+    cache = np.arange(np.prod(g["cache_shape"]), dtype=np.float32).reshape(g["cache_shape"])
+    y = orc.repeat_kv(cache, g["ctx_len"], g["layer"], g["head_num"], g["max_k_len"])
+    assert y.reshape(-1).tolist() == g["expected"]

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 DEV, F16 = "cuda", torch.float16
 
 
-def _engine(llmie, rng, nh, kvh, hs, I, L, max_seq, bs, kv8):
+def _engine(llmie, rng, nh, kvh, hs, I, L, max_seq, bs, kv8, ks=1 / 32, vs=1 / 16):
     H, QKV = nh * hs, (nh + 2 * kvh) * hs
     u = lambda shape, s: torch.from_numpy((rng.uniform(-1, 1, shape) * s).astype(np.float32)).to(DEV).to(F16)
     layers = [dict(attn_norm=u((H,), 0.2) + 1, qkv=dict(data=u((QKV, H), 2 / np.sqrt(H))), o=dict(data=u((H, H), 2 / np.sqrt(H))),
@@ -18,17 +18,19 @@ def _engine(llmie, rng, nh, kvh, hs, I, L, max_seq, bs, kv8):
               for _ in range(L)]
     cfg = dict(head_num=nh, kv_head_num=kvh, head_size=hs, inter_size=I, num_layers=L, vocab_size=100, max_seq_len=max_seq,
                max_batch=bs, rotary_dim=hs, rotary_base=10000.0, rms_eps=1e-5, dtype=llmie.F16, wfmt=llmie.W_F16, int4_group=128,
-               kv_fmt=llmie.KV_FP8 if kv8 else llmie.KV_NATIVE, k_scale=1 / 32, v_scale=1 / 16)
+               kv_fmt=llmie.KV_FP8 if kv8 else llmie.KV_NATIVE, k_scale=ks, v_scale=vs)
     return llmie.Decoder(cfg, layers)
 
 
 @pytest.mark.parametrize("name,nh,kvh,hs,I,L,bs,max_seq,step,kv8", [
     ("b1", 8, 8, 128, 1024, 2, 1, 600, 530, False), ("b3_gqa", 16, 4, 128, 1024, 2, 3, 384, 300, False),
     ("b20_splitk", 8, 8, 128, 1024, 2, 20, 300, 257, False), ("b2_fp8kv", 8, 8, 128, 1024, 2, 2, 700, 640, True),
-    ("b12_fp8kv_splitk", 8, 8, 128, 768, 1, 12, 256, 129, True), ("first_page", 8, 8, 128, 512, 1, 2, 256, 5, False)])
+    ("b12_fp8kv_splitk", 8, 8, 128, 768, 1, 12, 256, 129, True), ("first_page", 8, 8, 128, 512, 1, 2, 256, 5, False),
+    ("b2_fp8kv_np2scales", 8, 8, 128, 1024, 2, 2, 700, 640, True)])
 def test_paged_decode_is_bit_identical_to_dense(llmie, name, nh, kvh, hs, I, L, bs, max_seq, step, kv8):
     rng = np.random.default_rng(71)
-    dec = _engine(llmie, rng, nh, kvh, hs, I, L, max_seq, bs, kv8)
+    ks, vs = (0.037, 0.021) if "np2" in name else (1 / 32, 1 / 16)
+    dec = _engine(llmie, rng, nh, kvh, hs, I, L, max_seq, bs, kv8, ks, vs)
     H = nh * hs
     if kv8:
         kd = torch.randint(0, 0x58, (L, bs, kvh, max_seq, hs), device=DEV, dtype=torch.uint8)

@@ -251,10 +251,11 @@ def _fp8_lin(x, wdeq):
     return orc.linear(xdeq * xs[:, None], wdeq)
 
 
-@pytest.mark.parametrize("bs", [1, 4, 20, 72])
+@pytest.mark.parametrize("bs", [1, 2, 4, 8, 16, 20, 32, 72, 128])
 def test_fp8_decoder_matches_oracle_composition(llmie, bs):
     """one 7B-geometry layer, fp8 weights + per-token fp8 activations, against the oracle's kernels composed in numpy
-    with the activation quantisation emulated (batch 1/4: GEMV path, 20/72: MFMA path)"""
+    with the activation quantisation emulated, at the batch sizes of BASELINE configs[4]'s sweep (1 / 2: GEMV path; 4 / 8 / 16:
+    packed e4m3 path up to its upper end; 20 / 32: skinny split-K; 72 / 128: the 128-row split-K form incl. its two-pass edge)"""
     rng = np.random.default_rng(54)
     nh, hs, I, L, max_seq, step = 32, 128, 11008, 1, 64, 33
     H, QKV = nh * hs, 3 * nh * hs
