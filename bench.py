@@ -286,7 +286,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the int8/int4/short-context side measurements")
     ap.add_argument("--only", default="", help="profiling aid: run ONE configuration and print a short line: "
-                                               "decode:<f16|int8|int4|fp8>:<batch>:<ctx>[:kvfp8] or prefill:<f16|fp8>:<batch>:<seq>")
+                                               "decode:<f16|int8|int4|fp8>:<batch>:<ctx>[:kvfp8] or prefill:<f16|int8|int4|fp8>:<batch>:<seq>")
     ap.add_argument("--dry-run", action="store_true",
                     help="replica plumbing only (no GPU, no kernels): simulated per-rank times through the real launcher/aggregation")
     args = ap.parse_args()
@@ -603,6 +603,19 @@ def main():
         record_prefill("prefill_f16_b8_s512", 8, 512)
         record_prefill("prefill_f16_b1_s128", 1, 128)   # BASELINE configs[1] shape (all 32 layers)
         q8 = quantize_layers(torch, llmie, weights["layers"], "int8")
+        # the int8 half of the metric's prefill side (round 3): weight-only int8 through the eight-phase GEMM's int8 B-operand form
+        p8p = record_prefill("prefill_int8_b1_s2048", 1, 2048, "int8", q8, profile=True)
+        record_prefill("prefill_int8_b8_s512", 8, 512, "int8", q8)
+        record_prefill("prefill_int8_b1_s128", 1, 128, "int8", q8)
+        for nm in ("b1_s2048", "b8_s512", "b1_s128"):
+            extra["prefill_int8_" + nm]["vs_f16"] = round(extra["prefill_int8_" + nm]["tokens_per_s"] / extra["prefill_f16_" + nm]["tokens_per_s"], 4)
+        if p8p and p8p.get("gate_up_swiglu", (0, 0))[1]:
+            ms_, n_ = p8p["gate_up_swiglu"]
+            out["roofline_prefill_int8"] = roofline_block(
+                "gemm8p_kernel<fp16 x int8,SwiGLU,WQ=8>: raw int8 weight tiles by LDS-DMA, de-quantised at fragment read (gate/up projection + SwiGLU epilogue), T = 2048",
+                "mfma", 2.0 * 2048 * 2 * cfg["inter_size"] * H, ms_ / n_ * 1e3, n_, 2500.0, "TFLOP/s", "prefill_int8_b1_s2048")
+            out["roofline_prefill_int8"]["whole_pass"] = dict(extra["prefill_int8_b1_s2048"])
+            out["roofline_prefill_int8"]["ops_us_per_launch"] = {op: round(ms / n * 1e3, 2) for op, (ms, n) in p8p.items() if n}
         record("decode_int8_b1_ctx2048", "int8", q8, 1, 2048, 1.0)
         p8 = record("decode_int8_b32_ctx128", "int8", q8, 32, 128, 1.0, profile=True)   # BASELINE configs[3]
         if p8 and p8.get("gate_up_swiglu", (0, 0))[1]:
@@ -622,6 +635,8 @@ def main():
         q4 = quantize_layers(torch, llmie, weights["layers"], "int4")
         record("decode_int4_b1_ctx2048", "int4", q4, 1, 2048, 0.5 + 2.0 / 128)
         record("decode_int4_b32_ctx128", "int4", q4, 32, 128, 0.5 + 2.0 / 128)
+        record_prefill("prefill_int4_b1_s2048", 1, 2048, "int4", q4)   # fp16 image of one matrix at a time + the fp16 GEMM
+        record_prefill("prefill_int4_b8_s512", 8, 512, "int4", q4)
         del q4
         torch.cuda.empty_cache()
         q8f = quantize_layers(torch, llmie, weights["layers"], "fp8")   # BASELINE configs[4]: fp8 batch sweep at ctx 512

@@ -708,7 +708,7 @@ extern "C" int llmie_decoder_forward_paged(llmie_decoder *dec, const void *hidde
     return rc;
 }
 
-static size_t prefill_carve(const llmie_decoder_config *c, int T, int B, size_t *o /*[9]*/) {
+static size_t prefill_carve(const llmie_decoder_config *c, int T, int B, size_t *o /*[10]*/) {
     const size_t e = 2, H = static_cast<size_t>(c->head_num) * c->head_size;
     const size_t QKV = static_cast<size_t>(c->head_num + 2 * c->kv_head_num) * c->head_size, I = c->inter_size;
     Carve k;
@@ -722,12 +722,25 @@ static size_t prefill_carve(const llmie_decoder_config *c, int T, int B, size_t 
     // fp8 engines: per-token e4m3 image + scales of the activation matrix entering each projection
     o[7] = k.take(c->wfmt == LLMIE_W_FP8 ? llmie_linear_fp8_workspace_bytes(T, static_cast<int>(I > H ? I : H), 0) : 256);
     o[8] = k.take(engine_slab_floats(c, T < 192 ? T : 192) * sizeof(float) + 256);   // split-K slabs (short prefills; fp8 passes)
+    // int8 / int4 engines at prefill-sized T: room for the fp16 image of the largest matrix (projections without an in-kernel
+    // de-quantising form: int4, and int8 shapes whose 256-row grid does not fill the chip)
+    size_t dq = 0;
+    if (c->wfmt == LLMIE_W_INT8 || c->wfmt == LLMIE_W_INT4) {
+        const int bits = c->wfmt == LLMIE_W_INT8 ? 8 : 4;
+        const size_t shapes[4][2] = {{H, QKV}, {H, H}, {H, 2 * I}, {I, H}};
+        (void)bits;
+        for (const auto &sh : shapes) {   // (any T: shapes outside the quantised kernels' K sub-blocks take the image at every size)
+            const size_t b = sh[0] * sh[1] * sizeof(half_t);
+            dq = b > dq ? b : dq;
+        }
+    }
+    o[9] = k.take(dq + 256);
     return k.off;
 }
 
 extern "C" size_t llmie_decoder_prefill_workspace_bytes(const llmie_decoder_config *cfg, int max_tokens, int max_batch) {
     if (!config_ok(cfg) || max_tokens <= 0 || max_batch <= 0) return 0;
-    size_t o[9];
+    size_t o[10];
     return prefill_carve(cfg, max_tokens, max_batch, o);
 }
 
@@ -742,9 +755,12 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
                   "decoder_prefill: bad shape batch=%d tokens=%d max_q_len=%d", batch, num_tokens, max_q_len);
     LLMIE_REQUIRE(num_tokens <= static_cast<long long>(batch) * max_q_len, "decoder_prefill: num_tokens > batch*max_q_len");
     const bool fp8 = c.wfmt == LLMIE_W_FP8;
-    if (c.dtype != LLMIE_F16 || (c.wfmt != LLMIE_W_F16 && !fp8) || c.head_size != 128)
-        LLMIE_UNSUPPORTED("decoder_prefill: fp16 activations + fp16 or fp8 weights + head_size 128 only (use the per-kernel path)");
-    size_t o[9];
+    // weight-only int8 / int4 (round 3): the same layer sequence on the quantised matrices -- the projections de-quantise inside
+    // the GEMM (int8: gemm8p.cuh WQ form) or through an fp16 image of one matrix at a time (int4; quant_linear.hip)
+    const int wqbits = c.wfmt == LLMIE_W_INT8 ? 8 : (c.wfmt == LLMIE_W_INT4 ? 4 : 0);
+    if (c.dtype != LLMIE_F16 || (c.wfmt != LLMIE_W_F16 && !fp8 && !wqbits) || c.head_size != 128)
+        LLMIE_UNSUPPORTED("decoder_prefill: fp16 activations + fp16 / int8 / int4 / fp8 weights + head_size 128 only (use the per-kernel path)");
+    size_t o[10];
     const size_t need = prefill_carve(&c, num_tokens, batch, o);
     if (workspace_bytes < need || reinterpret_cast<uintptr_t>(workspace) % 256) {
         set_error("decoder_prefill: workspace too small or unaligned (%zu < %zu)", workspace_bytes, need);
@@ -767,8 +783,13 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
     void *f8ws = base + o[7];
     const size_t f8ws_bytes = fp8 ? llmie_linear_fp8_workspace_bytes(T, I > H ? I : H, 0) : 0;
     const SlabWs slabs{reinterpret_cast<float *>(base + o[8]), engine_slab_floats(&c, T < 192 ? T : 192)};
+    void *deq = base + o[9];
+    const size_t deq_bytes = need - o[9];
     // y = x . W^T (+ residual) in the engine's weight format (fp8: per-token e4m3 activations, fp8 MFMA)
     auto proj = [&](const half_t *x, const llmie_matrix &w, half_t *y, int K, int N, const half_t *residual) -> int {
+        if (wqbits)
+            return linear_wq(wqbits, x, w.data, (const half_t *)w.scale, y, T, K, N, c.int4_group, EPI_NONE_, nullptr, residual, nullptr,
+                             nullptr, 0.f, slabs, st, deq, deq_bytes);
         if (fp8)
             return linear_fp8(x, (const uint8_t *)w.data, (const float *)w.scale, y, T, K, N, nullptr, residual, f8ws, f8ws_bytes,
                               slabs, st);
@@ -781,30 +802,34 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
     // decode path -- every projection leaves split-K slabs, the O and down slabs are consumed by the row kernel (reduction +
     // residual stream + the next RMSNorm), the gate/up slabs by the SwiGLU finalize: 9 launches per layer instead of 13.
     static const bool short_off = getenv("LLMIE_NO_FUSED_SHORT_PREFILL") != nullptr;
-    if (!short_off && !fp8 && T <= 128 && H % 256 == 0 && I % 256 == 0 && H >= 512 && I >= 512 && splitk_rownorm_eligible(H)) {
-        const SlabScale none{nullptr, nullptr, nullptr};
+    const int sbits = wqbits ? wqbits : 16;   // split-K kernels' weight-format code
+    const bool short_fmt_ok = !fp8 && (wqbits != 4 || (c.int4_group == 128 && T <= 64));   // int4 split-K form: 64 rows, group 128
+    if (!short_off && short_fmt_ok && T <= 128 && H % 256 == 0 && I % 256 == 0 && H >= 512 && I >= 512 && splitk_rownorm_eligible(H)) {
+        // int8: row scales applied by the slab consumers; int4: group scales applied inside the split-K kernel
+        auto sc_of = [&](const llmie_matrix &m) { return SlabScale{wqbits == 8 ? static_cast<const half_t *>(m.scale) : nullptr, nullptr, nullptr}; };
+        auto gs_of = [&](const llmie_matrix &m) { return wqbits == 4 ? static_cast<const half_t *>(m.scale) : nullptr; };
         TIMED(LLMIE_OP_ATTN_NORM, llmie_rmsnorm(h, resid, dec->layers[0].attn_norm_gamma, c.rms_eps, T, H, LLMIE_F16, stream));
         for (int l = 0; l < c.num_layers; ++l) {
             const llmie_layer_weights &w = dec->layers[l];
             const bool last = l + 1 == c.num_layers;
             SplitKSlabs sk;
-            TIMED(LLMIE_OP_QKV_GEMM, linear_splitk_partial(16, h, w.qkv.data, T, H, QKV, st, &sk, slabs));
-            TIMED(LLMIE_OP_QKV_GEMM, splitk_finalize(sk, none, qkv, EPI_NONE_, nullptr, nullptr, st));
+            TIMED(LLMIE_OP_QKV_GEMM, linear_splitk_partial(sbits, h, w.qkv.data, T, H, QKV, st, &sk, slabs, gs_of(w.qkv)));
+            TIMED(LLMIE_OP_QKV_GEMM, splitk_finalize(sk, sc_of(w.qkv), qkv, EPI_NONE_, nullptr, nullptr, st));
             TIMED(LLMIE_OP_MHA, prefill_attention_f16(qkv, (const half_t *)w.qkv.bias, k_cache, v_cache, attn, cum,
                                                       history_lengths, dec->rope_table, l, batch, T, max_q_len, c.head_num,
                                                       c.kv_head_num, c.head_size, c.max_seq_len, c.rotary_dim, st,
                                                       c.kv_fmt == LLMIE_KV_FP8, c.k_scale > 0.f ? c.k_scale : 1.f,
                                                       c.v_scale > 0.f ? c.v_scale : 1.f, dec->page_table, dec->max_pages, dec->num_pages));
-            TIMED(LLMIE_OP_O_GEMM, linear_splitk_partial(16, attn, w.o.data, T, H, H, st, &sk, slabs));
+            TIMED(LLMIE_OP_O_GEMM, linear_splitk_partial(sbits, attn, w.o.data, T, H, H, st, &sk, slabs, gs_of(w.o)));
             // context_decoder.cpp: h += resid; resid = h; h += o.bias; h = rmsnorm(h, ffn_gamma)
-            TIMED(LLMIE_OP_FFN_NORM, splitk_rownorm(sk, none, static_cast<const half_t *>(w.o.bias), resid,
+            TIMED(LLMIE_OP_FFN_NORM, splitk_rownorm(sk, sc_of(w.o), static_cast<const half_t *>(w.o.bias), resid,
                                                     static_cast<const half_t *>(w.ffn_norm_gamma), c.rms_eps, h, nullptr, nullptr, st));
-            TIMED(LLMIE_OP_GATE_UP_SWIGLU, linear_splitk_partial(16, h, w.gate_up.data, T, H, 2 * I, st, &sk, slabs));
-            TIMED(LLMIE_OP_GATE_UP_SWIGLU, splitk_finalize(sk, none, act, EPI_SWIGLU_, nullptr, nullptr, st));
-            TIMED(LLMIE_OP_DOWN_GEMM, linear_splitk_partial(16, act, w.down.data, T, I, H, st, &sk, slabs));
+            TIMED(LLMIE_OP_GATE_UP_SWIGLU, linear_splitk_partial(sbits, h, w.gate_up.data, T, H, 2 * I, st, &sk, slabs, gs_of(w.gate_up)));
+            TIMED(LLMIE_OP_GATE_UP_SWIGLU, splitk_finalize(sk, sc_of(w.gate_up), act, EPI_SWIGLU_, nullptr, nullptr, st));
+            TIMED(LLMIE_OP_DOWN_GEMM, linear_splitk_partial(sbits, act, w.down.data, T, I, H, st, &sk, slabs, gs_of(w.down)));
             // h = act.Wd^T + resid, then the next layer's resid = h; h = rmsnorm(h) (last layer: h stays un-normalised)
             const void *next_gamma = last ? nullptr : dec->layers[l + 1].attn_norm_gamma;
-            TIMED(LLMIE_OP_ATTN_NORM, splitk_rownorm(sk, none, nullptr, resid, static_cast<const half_t *>(next_gamma), c.rms_eps, h,
+            TIMED(LLMIE_OP_ATTN_NORM, splitk_rownorm(sk, sc_of(w.down), nullptr, resid, static_cast<const half_t *>(next_gamma), c.rms_eps, h,
                                                      nullptr, nullptr, st));
         }
         return LLMIE_OK;
@@ -845,7 +870,10 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
         TIMED(LLMIE_OP_FFN_NORM, llmie_fused_add_bias_residual_rmsnorm(resid, h, w.o.bias, w.ffn_norm_gamma, c.rms_eps, T, H,
                                                                        LLMIE_F16, stream));
         // ffn.cpp:105-122: act = silu(h.Wg^T) * (h.Wu^T); SwiGLU fused into the projection's epilogue where a fused form exists
-        if (!fp8 && (T <= 192 || gemm256_swiglu_fills(T, 2 * I))) {
+        if (wqbits && (T < kWqPrefillRows || gemm256_swiglu_fills(T, 2 * I))) {
+            TIMED(LLMIE_OP_GATE_UP_SWIGLU, linear_wq(wqbits, h, w.gate_up.data, (const half_t *)w.gate_up.scale, act, T, H, 2 * I, c.int4_group,
+                                                     EPI_SWIGLU_, nullptr, nullptr, nullptr, nullptr, 0.f, slabs, st, deq, deq_bytes));
+        } else if (!wqbits && !fp8 && (T <= 192 || gemm256_swiglu_fills(T, 2 * I))) {
             TIMED(LLMIE_OP_GATE_UP_SWIGLU, linear_f16_nk(h, (const half_t *)w.gate_up.data, act, T, H, 2 * I, EPI_SWIGLU_, nullptr, nullptr, slabs, st));
         } else if (fp8 && gemm256_swiglu_fills(T, 2 * I) && H % 128 == 0 && reinterpret_cast<uintptr_t>(w.gate_up.data) % 16 == 0) {
             TIMED(LLMIE_OP_GATE_UP_SWIGLU, llmie_linear_fp8_swiglu(h, (const uint8_t *)w.gate_up.data, (const float *)w.gate_up.scale,

@@ -24,11 +24,14 @@ typedef int intx8 __attribute__((ext_vector_type(8)));
 
 // Epilogue shared by the 256-row kernels (this file and gemm8p.cuh): acc[i][j] of wave (wr, wc): lane (r, q) holds
 // C[m0 + wr*128 + i*16 + r][n0 + wcol + j*16 + 4q + e]; SwiGLU: acc[i][jj] = gate, acc[i][2 + jj] = up of column n0 + wcol + 16 jj + 4q + e.
-template <bool FP8, bool HAS_EPI, int WN, bool SWIGLU>
+// WQ = 8 (gemm8p.cuh, int8 weights): `wscale` points at the fp16 per-row scales of W, applied to the fp32 sums before bias / residual.
+template <bool FP8, bool HAS_EPI, int WN, bool SWIGLU, int WQ = 0>
 __device__ __forceinline__ void g256_store(floatx4 (&acc)[8][WN], half_t *C, int M, int N, size_t ldc, int m0, int n0, int wr, int wcol,
                                            int r, int q, const half_t *__restrict__ bias, const half_t *residual,
                                            const float *__restrict__ xscale, const float *__restrict__ wscale) {
     const int half_n = N >> 1;
+    const half_t *hscale = reinterpret_cast<const half_t *>(wscale);
+    (void)hscale;
     if constexpr (SWIGLU) {
         // acc[i][jj] = gate, acc[i][WN / 2 + jj] = up of C columns n0 + wcol + 16 jj + 4q + e
 #pragma unroll
@@ -46,6 +49,10 @@ __device__ __forceinline__ void g256_store(floatx4 (&acc)[8][WN], half_t *C, int
                         const float xsm = xscale[m];
                         gt *= wscale[min(n + e, half_n - 1)] * xsm;
                         up *= wscale[half_n + min(n + e, half_n - 1)] * xsm;
+                    }
+                    if constexpr (WQ != 0) {
+                        gt *= to_f32(hscale[min(n + e, half_n - 1)]);
+                        up *= to_f32(hscale[half_n + min(n + e, half_n - 1)]);
                     }
                     // the unfused sequence rounds gate and up to fp16 before SiluAndMul: keep the same roundings
                     gt = to_f32(from_f32<half_t>(gt));
@@ -80,6 +87,11 @@ __device__ __forceinline__ void g256_store(floatx4 (&acc)[8][WN], half_t *C, int
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] *= ws[e] * xsm;
                 }
+                if constexpr (WQ != 0) {
+                    const half4_t ws = *reinterpret_cast<const half4_t *>(hscale + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= to_f32(ws[e]);
+                }
                 if (HAS_EPI) {
                     if (bias) {
                         const half4_t b4 = *reinterpret_cast<const half4_t *>(bias + n);
@@ -100,6 +112,7 @@ __device__ __forceinline__ void g256_store(floatx4 (&acc)[8][WN], half_t *C, int
                     if (n + e < N) {
                         float v = acc[i][j][e];
                         if constexpr (FP8) v *= wscale[n + e] * xscale[m];
+                        if constexpr (WQ != 0) v *= to_f32(hscale[n + e]);
                         if (HAS_EPI) {
                             if (bias) v += to_f32(bias[n + e]);
                             if (residual) v += to_f32(residual[static_cast<size_t>(m) * ldc + n + e]);

@@ -53,6 +53,47 @@ template <bool FP8> __device__ __forceinline__ void g8_mma(floatx4 &acc, const G
     if constexpr (FP8) acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w.v, x.v, acc, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
     else acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.k[k], x.k[k], acc, 0, 0, 0);
 }
+// ---- weight-only int8 B operand (WQ = 8; round 3: prefill of int8 engines, context_decoder.cpp:58-199 on int8 [N, K] weights) ----
+// The weight tile travels HBM/L2 -> LDS as RAW int8 (64 bytes per row and 64-deep k-tile: half the DMA and LDS-fill bytes of the
+// fp16 form) and is de-quantised when a wave reads its fragment: one ds_read_b128 = the lane's 16 weights of one row, k = 16 q ..
+// 16 q + 15 of the k-tile; bytes 0-7 feed k-step 0 and bytes 8-15 k-step 1, and the activation fragments are read with the SAME k
+// assignment (16-byte chunks 2q and 2q + 1 of the row, the mapping the e4m3 form already uses) -- any k order is a valid
+// contraction as long as both operands agree.  De-quantisation is exact: byte ^ 0x80 under the fp16 exponent 0x64 is 1152 + w, and
+// a packed fp16 subtract of 1152 leaves w (integers below 2048 are exact in fp16); the per-row scale meets the fp32 accumulator in
+// the epilogue, so the numerics are "fp16 activations x integer weights, fp32 accumulate, one scale, one rounding" -- what the
+// int8 decode kernels compute.  LDS image of a B half: 128 rows x 64 B; slot c of row r holds source chunk c ^ ((-(r >> 2)) & 3)
+// (applied on the DMA source address): the 16 lanes of every ds_read_b128 service group then hit 16 different 16-byte bank groups.
+__device__ __forceinline__ unsigned g8_q8_slot(int row, int chunk) { return static_cast<unsigned>((chunk ^ (-(row >> 2))) & 3); }
+__device__ __forceinline__ void g8_read_q8(G8Frag<false> &f, const unsigned char *p) {
+    const uint4_t w = *reinterpret_cast<const uint4_t *>(p);
+    const half2_t off = {static_cast<half_t>(1152.f), static_cast<half_t>(1152.f)};
+    half2_t h[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned v = w[i] ^ 0x80808080u;
+        h[2 * i] = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(0x64646464u, v, 0x04010400u)) - off;       // {0x64, b1, 0x64, b0}
+        h[2 * i + 1] = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(0x64646464u, v, 0x04030402u)) - off;   // {0x64, b3, 0x64, b2}
+    }
+    f.k[0] = half8_t{h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]};
+    f.k[1] = half8_t{h[4][0], h[4][1], h[5][0], h[5][1], h[6][0], h[6][1], h[7][0], h[7][1]};
+}
+// s_waitcnt vmcnt(n) for a run-time n (tails and prologues only; the steady state uses immediates)
+__device__ __forceinline__ void g8_wait_vm(int n) {
+    switch (n < 0 ? 0 : (n > 10 ? 10 : n)) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    }
+}
+
 // Placement pins (no instructions): the MFMAs of a phase read fragments that pass through g8_pin AFTER the phase's lgkmcnt(0) and
 // write accumulators that pass through g8_pin BEFORE the closing barrier, so no IR pass can sink them out of the phase or hoist
 // them into the read segment (sched_barrier only binds the machine scheduler; without the pins the e4m3 form had its MFMAs sunk
@@ -73,13 +114,17 @@ __device__ __forceinline__ void g8_wait_groups(int groups) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <bool FP8, bool HAS_EPI, bool SWIGLU = false>
+// WQ = 8: W is int8 [N, K] (row pitch K bytes) and wscale points at the fp16 per-row scales; X stays fp16 (FP8 must be false).
+// DMA groups of the weight pieces are then ONE wave instruction per wave (8 KiB) instead of two, so the counted waits differ per
+// phase: behind phase (u, s) the groups 4u+s+3 .. 4u+s+7 stay in flight = A B A B A (8 instructions) for even s, B A B A B (7) for odd.
+template <bool FP8, bool HAS_EPI, bool SWIGLU = false, int WQ = 0>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const void *__restrict__ Xv, const void *__restrict__ Wv, half_t *C, int M, int N,
                                                      int K, const half_t *__restrict__ bias, const half_t *residual, int tiles_n,
                                                      const float *__restrict__ xscale, const float *__restrict__ wscale,
                                                      int ldc_arg = 0, int group_m = 0, int col0 = 0) {
     // col0 (SwiGLU form): first output column of this launch's range (a launch over columns [col0, col0 + tiles_n * 128) of C[M, I])
     static_assert(!SWIGLU || !HAS_EPI, "SwiGLU form: no bias / residual");
+    static_assert(WQ == 0 || (WQ == 8 && !FP8), "WQ: 0 (operands as they are) or 8 (int8 weights under fp16 activations)");
     const size_t ldc = ldc_arg ? ldc_arg : N;
     constexpr int ES = FP8 ? 1 : 2, BK = 128 / ES;
     constexpr int BN = SWIGLU ? 128 : 256;
@@ -111,8 +156,10 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void *__restrict__ Xv
     //      3 = A rows 64-127.  A group = 16 pieces of 8 rows x 128 B; this wave moves pieces pi = i*8 + wave, i = 0, 1.
     //      lane -> row lane/8 of the piece, LDS slot lane%8 <- source chunk slot ^ (row & 7)  (swizzle on the source side)
     const size_t row_bytes = static_cast<size_t>(K) * ES;
+    const size_t wrow_bytes = WQ ? static_cast<size_t>(K) : row_bytes;
+    constexpr unsigned WKT_BYTES = WQ ? 64 : 128;   // bytes of a weight row per k-tile
     const unsigned char *xbase = X + static_cast<size_t>(m0) * row_bytes;   // wave-uniform bases; the per-lane part is 32-bit
-    const unsigned char *wbase = W + static_cast<size_t>(n0) * row_bytes;
+    const unsigned char *wbase = W + static_cast<size_t>(n0) * wrow_bytes;
     typedef __attribute__((address_space(3))) void *lptr_t;
     const unsigned lds_addr = static_cast<unsigned>(reinterpret_cast<size_t>((lptr_t)lds));   // LDS byte address of the image
     unsigned voff[4][2], ldst[4][2];
@@ -120,6 +167,26 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void *__restrict__ Xv
     for (int kind = 0; kind < 4; ++kind)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            if constexpr (WQ != 0) {
+                if (kind == 1 || kind == 2) {   // int8 weight piece: 16 rows x 64 B per wave instruction, one per wave (i = 0)
+                    const int pi = wave;
+                    int half, row0;
+                    if (SWIGLU) {
+                        half = 2 + (kind - 1);
+                        row0 = pi * 16;
+                    } else {
+                        half = 2 + (pi >> 2);
+                        row0 = ((pi >> 1) & 1) * 64 + (kind - 1) * 32 + (pi & 1) * 16;
+                    }
+                    const int row = row0 + (lane >> 2), chunk = static_cast<int>(g8_q8_slot(row, lane & 3));
+                    long grow;
+                    if (SWIGLU) grow = static_cast<long>(half - 2) * half_n + min(n0 + row, half_n - 1) - n0;
+                    else grow = min(n0 + (half - 2) * 128 + row, N - 1) - n0;
+                    voff[kind][i] = static_cast<unsigned>(grow * static_cast<long>(wrow_bytes) + chunk * 16);
+                    ldst[kind][i] = __builtin_amdgcn_readfirstlane(lds_addr + half * HALF_BYTES + row0 * 64);
+                    continue;
+                }
+            }
             const int pi = i * 8 + wave;
             int half, row0;   // LDS half (0..3) and first row of the piece inside it
             if (kind == 0 || kind == 3) {
@@ -142,14 +209,22 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void *__restrict__ Xv
         }
     auto issue = [&](auto kind_, int kt, unsigned stage) {
         constexpr int kind = decltype(kind_)::value;
-        const unsigned char *base = ((kind == 0 || kind == 3) ? xbase : wbase) + static_cast<size_t>(kt) * 128;
+        constexpr bool is_a = kind == 0 || kind == 3;
+        const unsigned char *base = is_a ? xbase + static_cast<size_t>(kt) * 128 : wbase + static_cast<size_t>(kt) * WKT_BYTES;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) g8_dma16(voff[kind][i], base, ldst[kind][i] + stage * STAGE_BYTES);
+        for (int i = 0; i < ((WQ != 0 && !is_a) ? 1 : 2); ++i) g8_dma16(voff[kind][i], base, ldst[kind][i] + stage * STAGE_BYTES);
     };
     using K0 = std::integral_constant<int, 0>;
     using K1 = std::integral_constant<int, 1>;
     using K2 = std::integral_constant<int, 2>;
     using K3 = std::integral_constant<int, 3>;
+    // WQ: DMA wave instructions of the groups (first, last] still in flight; group g is a weight piece (1) for even g, an
+    // activation piece (2) for odd g (order {1, 0, 2, 3} inside a k-tile)
+    auto q8_inflight = [](int first, int last) {
+        int n = 0;
+        for (int g = first + 1; g <= last; ++g) n += (g & 1) ? 2 : 1;
+        return n;
+    };
 
     floatx4 acc[8][4];
 #pragma unroll
@@ -159,11 +234,14 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void *__restrict__ Xv
 
     // ---- fragment reads: 16-byte piece k (0, 1) of row `row`: fp16 -> chunk k*4 + q (k-step k), e4m3 -> chunk 2q + k (one 128-deep step)
     const int wcol = SWIGLU ? wc * 32 : wc * 64;
-    const unsigned sw0 = static_cast<unsigned>(((FP8 ? 2 * q : q) ^ (r & 7)) << 4), sw1 = static_cast<unsigned>(((FP8 ? 2 * q + 1 : 4 + q) ^ (r & 7)) << 4);
+    constexpr bool K16 = FP8 || WQ != 0;   // lane q owns k = 16 q .. 16 q + 15 of the k-tile (chunks 2q, 2q + 1) instead of 8 q .. and 32 + 8 q ..
+    const unsigned sw0 = static_cast<unsigned>(((K16 ? 2 * q : q) ^ (r & 7)) << 4), sw1 = static_cast<unsigned>(((K16 ? 2 * q + 1 : 4 + q) ^ (r & 7)) << 4);
     const unsigned a_lane = wr * HALF_BYTES + r * 128;   // + stage, + (ih*64 + i*16) * 128, + sw
     // B piece jh, fragment jj: plain -> half 2 + (wc >> 1), row (wc & 1)*64 + jh*32 + jj*16 + r;  SwiGLU -> half 2 + jh, row wc*32 + jj*16 + r
-    const unsigned b_lane = SWIGLU ? 2 * HALF_BYTES + (wc * 32 + r) * 128 : (2 + (wc >> 1)) * HALF_BYTES + ((wc & 1) * 64 + r) * 128;
-    constexpr unsigned B_PIECE = SWIGLU ? HALF_BYTES : 32 * 128;
+    constexpr unsigned BROW = WQ ? 64 : 128;   // bytes of a weight row in the LDS image
+    const unsigned b_lane = (SWIGLU ? 2 * HALF_BYTES + (wc * 32 + r) * BROW : (2 + (wc >> 1)) * HALF_BYTES + ((wc & 1) * 64 + r) * BROW) +
+                            (WQ ? (g8_q8_slot(r, q) << 4) : 0u);
+    constexpr unsigned B_PIECE = SWIGLU ? HALF_BYTES : 32 * BROW;
     G8Frag<FP8> fa[4], fb0[2][2], fb1[2];   // A piece (4 row tiles), B first piece of even / odd k-tiles, B second piece
     auto read_a = [&](unsigned stage, int ih) {
         const unsigned char *p = lds + stage * STAGE_BYTES + a_lane + ih * 64 * 128;
@@ -173,7 +251,10 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void *__restrict__ Xv
     auto read_b = [&](unsigned stage, int jh, G8Frag<FP8> (&f)[2]) {
         const unsigned char *p = lds + stage * STAGE_BYTES + b_lane + jh * B_PIECE;
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) g8_read<FP8>(f[jj], p + jj * 2048, sw0, sw1);
+        for (int jj = 0; jj < 2; ++jj) {
+            if constexpr (WQ != 0) g8_read_q8(f[jj], p + jj * 16 * BROW);
+            else g8_read<FP8>(f[jj], p + jj * 2048, sw0, sw1);
+        }
     };
     auto quadrant = [&](auto ih_, auto jh_, G8Frag<FP8> (&f)[2]) {
         constexpr int ih = decltype(ih_)::value, jh = decltype(jh_)::value;
@@ -196,7 +277,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void *__restrict__ Xv
     // ---- prologue: groups 0..6 (k-tile 0 whole, k-tile 1 without its last piece)
     issue(K1{}, 0, 0); issue(K0{}, 0, 0); issue(K2{}, 0, 0); issue(K3{}, 0, 0);
     if (KT > 1) { issue(K1{}, 1, 1); issue(K0{}, 1, 1); issue(K2{}, 1, 1); }
-    g8_wait_groups(min(7, G) - 2);   // groups 0 and 1 landed
+    if constexpr (WQ != 0) g8_wait_vm(q8_inflight(1, min(7, G) - 1));
+    else g8_wait_groups(min(7, G) - 2);   // groups 0 and 1 landed
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -223,7 +305,14 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void *__restrict__ Xv
         else if constexpr (s == 2) { if (STEADY || u + 2 < KT) issue(K0{}, u + 2, par); }
         else { if (STEADY || u + 2 < KT) issue(K2{}, u + 2, par); }
         // group 4u + s + 2 landed: the next phase reads it
-        if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        if constexpr (WQ != 0) {
+            if constexpr (STEADY) {
+                if constexpr ((s & 1) == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            } else {
+                g8_wait_vm(q8_inflight(4 * u + s + 2, min(4 * u + s + 7, G - 1)));
+            }
+        } else if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         else g8_wait_groups(G - (4 * u + s) - 3);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -258,7 +347,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void *__restrict__ Xv
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with the second row's last barrier
 
-    g256_store<FP8, HAS_EPI, 4, SWIGLU>(acc, C, M, N, ldc, m0, n0, wr, wcol, r, q, bias, residual, xscale, wscale);
+    g256_store<FP8, HAS_EPI, 4, SWIGLU, WQ>(acc, C, M, N, ldc, m0, n0, wr, wcol, r, q, bias, residual, xscale, wscale);
 }
 
 // ---- 256 x 128 tile in the same schedule, for projections whose 256-wide grid would leave CUs idle (N = 4096 at 2048 tokens).
@@ -281,12 +370,16 @@ __device__ __forceinline__ void g8_wait_instrs(int n) {   // n = DMA wave instru
 // SWIGLU: W = fused gate_up [2I, K]; the tile's 128 weight rows are 64 gate rows n0 .. and the 64 up rows I + n0 ..; wave wc
 // multiplies gate columns n0 + 16 wc .. + 16 and the matching up columns, C is [M, I] (N = 2I); col0 = first column of the launch.
 // Used for the columns that a whole number of 256-CU rounds of the 128-column SwiGLU tiles leaves over.
-template <bool FP8, bool HAS_EPI, bool SWIGLU = false>
+// WQ = 8 (int8 weights, as in gemm8p_kernel): the B group is one wave instruction per wave (128 rows x 64 B in the first half of its
+// slot); behind phase 2u the groups 3u+4 .. 3u+7 = A0 A1 B A0 stay in flight (7 instructions), behind phase 2u + 1 the groups
+// 3u+5 .. 3u+9 = A1 B A0 A1 B (8).
+template <bool FP8, bool HAS_EPI, bool SWIGLU = false, int WQ = 0>
 __global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict__ Xv, const void *__restrict__ Wv, half_t *C, int M, int N,
                                                           int K, const half_t *__restrict__ bias, const half_t *residual, int tiles_n,
                                                           const float *__restrict__ xscale, const float *__restrict__ wscale,
                                                           int ldc_arg = 0, int group_m = 0, int col0 = 0) {
     static_assert(!SWIGLU || !HAS_EPI, "SwiGLU form: no bias / residual");
+    static_assert(WQ == 0 || (WQ == 8 && !FP8), "WQ: 0 (operands as they are) or 8 (int8 weights under fp16 activations)");
     const int half_n = N >> 1;
     const size_t ldc = ldc_arg ? ldc_arg : N;
     constexpr int ES = FP8 ? 1 : 2, BK = 128 / ES;
@@ -315,15 +408,28 @@ __global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict
 
     // DMA plan: kind 0 = B, 1 = A0, 2 = A1 (the group order inside a k-tile); this wave moves pieces pi = i*8 + wave (8 slot rows each)
     const size_t row_bytes = static_cast<size_t>(K) * ES;
-    const unsigned char *xbase = X + static_cast<size_t>(m0) * row_bytes, *wbase = W + static_cast<size_t>(n0) * row_bytes;
+    const size_t wrow_bytes = WQ ? static_cast<size_t>(K) : row_bytes;
+    constexpr unsigned WKT_BYTES = WQ ? 64 : 128;   // bytes of a weight row per k-tile
+    const unsigned char *xbase = X + static_cast<size_t>(m0) * row_bytes, *wbase = W + static_cast<size_t>(n0) * wrow_bytes;
     typedef __attribute__((address_space(3))) void *lptr_t;
     const unsigned lds_addr = static_cast<unsigned>(reinterpret_cast<size_t>((lptr_t)lds));
     unsigned voff[3][2], ldst[2];
+    unsigned ldst_b = 0;   // WQ: LDS address of this wave's one weight piece (16 rows x 64 B)
+    if constexpr (WQ != 0) {
+        const int row = wave * 16 + (lane >> 2), chunk = static_cast<int>(g8_q8_slot(row, lane & 3));
+        ldst_b = __builtin_amdgcn_readfirstlane(lds_addr + wave * 1024);
+        long grow;
+        if constexpr (SWIGLU) grow = static_cast<long>(row >> 6) * half_n + min(n0 + (row & 63), half_n - 1) - n0;
+        else grow = min(n0 + row, N - 1) - n0;
+        voff[0][0] = static_cast<unsigned>(grow * static_cast<long>(wrow_bytes) + chunk * 16);
+        voff[0][1] = 0;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int pi = i * 8 + wave, row = pi * 8 + (lane >> 3), chunk = (lane & 7) ^ (row & 7);   // slot row of this lane
         ldst[i] = __builtin_amdgcn_readfirstlane(lds_addr + pi * 1024);
-        if constexpr (SWIGLU)   // slot rows 0-63: gate rows n0 + row; 64-127: up rows I + n0 + row - 64 (clamped inside their half)
+        if constexpr (WQ != 0) {
+        } else if constexpr (SWIGLU)   // slot rows 0-63: gate rows n0 + row; 64-127: up rows I + n0 + row - 64 (clamped inside their half)
             voff[0][i] = static_cast<unsigned>((static_cast<long>(row >> 6) * half_n + min(n0 + (row & 63), half_n - 1) - n0) * static_cast<long>(row_bytes) + chunk * 16);
         else
             voff[0][i] = static_cast<unsigned>(static_cast<long>(min(n0 + row, N - 1) - n0) * static_cast<long>(row_bytes) + chunk * 16);
@@ -335,13 +441,23 @@ __global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict
     }
     auto issue = [&](auto kind_, int kt, unsigned slot) {
         constexpr int kind = decltype(kind_)::value;
-        const unsigned char *base = (kind == 0 ? wbase : xbase) + static_cast<size_t>(kt) * 128;
+        if constexpr (WQ != 0 && kind == 0) {
+            g8_dma16(voff[0][0], wbase + static_cast<size_t>(kt) * WKT_BYTES, ldst_b + slot * SLOT_BYTES);
+        } else {
+            const unsigned char *base = (kind == 0 ? wbase : xbase) + static_cast<size_t>(kt) * 128;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) g8_dma16(voff[kind][i], base, ldst[i] + slot * SLOT_BYTES);
+            for (int i = 0; i < 2; ++i) g8_dma16(voff[kind][i], base, ldst[i] + slot * SLOT_BYTES);
+        }
     };
     using K0 = std::integral_constant<int, 0>;
     using K1 = std::integral_constant<int, 1>;
     using K2 = std::integral_constant<int, 2>;
+    // WQ: DMA wave instructions of the groups (first, last] still in flight; group g is the weight piece (1) when g % 3 == 0
+    auto q8_inflight = [](int first, int last) {
+        int n = 0;
+        for (int g = first + 1; g <= last; ++g) n += (g % 3 == 0) ? 1 : 2;
+        return n;
+    };
 
     floatx4 acc[8][2];
 #pragma unroll
@@ -350,10 +466,12 @@ __global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict
         for (int j = 0; j < 2; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     const int wcol = SWIGLU ? wc * 16 : wc * 32;
-    const unsigned sw0 = static_cast<unsigned>(((FP8 ? 2 * q : q) ^ (r & 7)) << 4), sw1 = static_cast<unsigned>(((FP8 ? 2 * q + 1 : 4 + q) ^ (r & 7)) << 4);
+    constexpr bool K16 = FP8 || WQ != 0;   // lane q owns k = 16 q .. 16 q + 15 of the k-tile (as in gemm8p_kernel)
+    const unsigned sw0 = static_cast<unsigned>(((K16 ? 2 * q : q) ^ (r & 7)) << 4), sw1 = static_cast<unsigned>(((K16 ? 2 * q + 1 : 4 + q) ^ (r & 7)) << 4);
     // B fragment jj: plain -> slot row wc*32 + jj*16 + r; SwiGLU -> jj = 0 the gate row wc*16 + r, jj = 1 the up row 64 + wc*16 + r
-    const unsigned a_lane = (wr * 64 + r) * 128, b_lane = ((SWIGLU ? wc * 16 : wc * 32) + r) * 128;
-    constexpr unsigned B_STEP = SWIGLU ? 64 * 128 : 16 * 128;
+    constexpr unsigned BROW = WQ ? 64 : 128;
+    const unsigned a_lane = (wr * 64 + r) * 128, b_lane = ((SWIGLU ? wc * 16 : wc * 32) + r) * BROW + (WQ ? (g8_q8_slot(r, q) << 4) : 0u);
+    constexpr unsigned B_STEP = SWIGLU ? 64 * BROW : 16 * BROW;
     G8Frag<FP8> fa[4], fb[3][2];   // A piece; B fragments of k-tiles u % 3 = 0, 1, 2
     auto read_a = [&](unsigned slot) {
         const unsigned char *p = lds + slot * SLOT_BYTES + a_lane;
@@ -363,7 +481,10 @@ __global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict
     auto read_b = [&](unsigned slot, G8Frag<FP8> (&f)[2]) {
         const unsigned char *p = lds + slot * SLOT_BYTES + b_lane;
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) g8_read<FP8>(f[jj], p + jj * B_STEP, sw0, sw1);
+        for (int jj = 0; jj < 2; ++jj) {
+            if constexpr (WQ != 0) g8_read_q8(f[jj], p + jj * B_STEP);
+            else g8_read<FP8>(f[jj], p + jj * B_STEP, sw0, sw1);
+        }
     };
     auto half_tile = [&](auto ih_, G8Frag<FP8> (&f)[2]) {
         constexpr int ih = decltype(ih_)::value;
@@ -387,7 +508,8 @@ __global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict
     issue(K0{}, 0, 0); issue(K1{}, 0, 1); issue(K2{}, 0, 2);
     if (KT > 1) { issue(K0{}, 1, 3); issue(K1{}, 1, 4); issue(K2{}, 1, 5); }
     if (KT > 2) issue(K0{}, 2, 6);
-    g8_wait_instrs(2 * (min(7, G) - 2));   // groups 0 and 1 landed
+    if constexpr (WQ != 0) g8_wait_vm(q8_inflight(1, min(7, G) - 1));
+    else g8_wait_instrs(2 * (min(7, G) - 2));   // groups 0 and 1 landed
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -404,14 +526,20 @@ __global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict
         if constexpr (s == 0) {
             read_a(3 * c + 1);
             if (STEADY || u + 2 < KT) issue(K1{}, u + 2, 3 * c2 + 1);
-            if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if constexpr (WQ != 0) {
+                if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                else g8_wait_vm(q8_inflight(3 * u + 3, min(3 * u + 7, G - 1)));
+            } else if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else g8_wait_instrs(2 * min(4, G - 3 * u - 4));
         } else {
             read_a(3 * c + 2);
             if (STEADY || u + 1 < KT) read_b(3 * c1, fb[c1]);
             if (STEADY || u + 2 < KT) issue(K2{}, u + 2, 3 * c2 + 2);
             if (STEADY || u + 3 < KT) issue(K0{}, u + 3, 3 * c);
-            if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            if constexpr (WQ != 0) {
+                if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else g8_wait_vm(q8_inflight(3 * u + 4, min(3 * u + 9, G - 1)));
+            } else if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             else g8_wait_instrs(2 * min(5, G - 3 * u - 5));
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -438,7 +566,7 @@ __global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict
     if (u + 1 < KT) { phase(std::integral_constant<int, 2>{}, u + 1, std::false_type{}); phase(std::integral_constant<int, 3>{}, u + 1, std::false_type{}); }
     if (wr == 0) __builtin_amdgcn_s_barrier();
 
-    g256_store<FP8, HAS_EPI, 2, SWIGLU>(acc, C, M, N, ldc, m0, n0, wr, wcol, r, q, bias, residual, xscale, wscale);
+    g256_store<FP8, HAS_EPI, 2, SWIGLU, WQ>(acc, C, M, N, ldc, m0, n0, wr, wcol, r, q, bias, residual, xscale, wscale);
 }
 
 }  // namespace llmie

@@ -544,10 +544,32 @@ static bool g8p_fits(int N, int K, bool fp8) {
     return (static_cast<size_t>(N) + 512) * K * (fp8 ? 1 : 2) < (size_t{1} << 32);
 }
 
-template <bool FP8, bool EPI, int WN>
+template <bool FP8, bool EPI, int WN, int WQ = 0>
 static void gemm256_launch_t(const void *x, const void *W, half_t *y, int M, int N, int K, const half_t *bias, const half_t *residual,
                              const float *xscale, const float *wscale, hipStream_t st, int ldc = 0) {
     constexpr int lds_bytes = 2 * (2 + WN / 2) * 128 * 128;
+    if constexpr (WQ != 0) {   // int8 weights: the eight-phase kernels only (callers check g8p_w8_eligible)
+        const int tmq = (M + 255) / 256, tnq = (N + 64 * WN - 1) / (64 * WN);
+        if constexpr (WN == 4) {
+            static const bool a8 = [] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm8p_kernel<false, EPI, false, WQ>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+                return true;
+            }();
+            (void)a8;
+            gemm8p_kernel<false, EPI, false, WQ><<<tmq * tnq, 512, lds_bytes, st>>>(x, W, y, M, N, K, bias, residual, tnq, xscale, wscale, ldc, g256_group_m());
+        } else {
+            constexpr int ring_bytes = 9 * 128 * 128;
+            static const bool a8 = [] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm8p_n128_kernel<false, EPI, false, WQ>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, ring_bytes);
+                return true;
+            }();
+            (void)a8;
+            gemm8p_n128_kernel<false, EPI, false, WQ><<<tmq * tnq, 512, ring_bytes, st>>>(x, W, y, M, N, K, bias, residual, tnq, xscale, wscale, ldc, g256_group_m());
+        }
+        return;
+    }
     static const bool attr_set = [] {   // once per process, thread-safe (function-local static initialisation)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm256_kernel<FP8, EPI, WN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -590,7 +612,7 @@ bool gemm256_swiglu_fills(int M, int two_inter) {
     return !off && two_inter % 8 == 0 && ((M + 255) / 256) * ((two_inter / 2 + 127) / 128) >= min_tiles;
 }
 void gemm256_swiglu_launch(bool fp8, const void *x, const void *W, half_t *y, int M, int two_inter, int K, const float *xscale,
-                           const float *wscale, hipStream_t st) {
+                           const float *wscale, hipStream_t st, int wq) {
     constexpr int lds_bytes = 2 * 4 * 128 * 128;
     static const bool attr_set = [] {   // once per process, thread-safe (function-local static initialisation)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm256_kernel<false, false, 4, true>),
@@ -627,6 +649,18 @@ void gemm256_swiglu_launch(bool fp8, const void *x, const void *W, half_t *y, in
                 }
             }
         }
+        if (wq) {   // int8 weights (wscale = their fp16 row scales)
+            static const bool attrq = [] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm8p_kernel<false, false, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm8p_n128_kernel<false, false, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, ring_bytes);
+                return true;
+            }();
+            (void)attrq;
+            gemm8p_kernel<false, false, true, 8><<<tm * a_tn, 512, lds_bytes, st>>>(x, W, y, M, two_inter, K, nullptr, nullptr, a_tn, nullptr, wscale, 0, g256_group_m(), 0);
+            if (b_tn)
+                gemm8p_n128_kernel<false, false, true, 8><<<tm * b_tn, 512, ring_bytes, st>>>(x, W, y, M, two_inter, K, nullptr, nullptr, b_tn, nullptr, wscale, 0, g256_group_m(), a_tn * 128);
+            return;
+        }
         if (fp8)
             gemm8p_kernel<true, false, true><<<tm * a_tn, 512, lds_bytes, st>>>(x, W, y, M, two_inter, K, nullptr, nullptr, a_tn, xscale, wscale, 0, g256_group_m(), 0);
         else
@@ -653,12 +687,23 @@ void gemm256_swiglu_launch(bool fp8, const void *x, const void *W, half_t *y, in
 
 // One launch over the column range [nb, nb + n) of the [M, N] output with 64*wn-column tiles.
 static void gemm256_range(bool fp8, int wn, const void *x, const void *W, half_t *y, int M, int N, int K, const half_t *bias,
-                          const half_t *residual, const float *xscale, const float *wscale, hipStream_t st, int nb, int n) {
+                          const half_t *residual, const float *xscale, const float *wscale, hipStream_t st, int nb, int n, int wq = 0) {
     const bool epi = bias || residual;
-    const void *Wr = static_cast<const unsigned char *>(W) + static_cast<size_t>(nb) * K * (fp8 ? 1 : 2);
+    const void *Wr = static_cast<const unsigned char *>(W) + static_cast<size_t>(nb) * K * ((fp8 || wq) ? 1 : 2);
     half_t *yr = y + nb;
     const half_t *br = bias ? bias + nb : nullptr, *rr = residual ? residual + nb : nullptr;
-    const float *wsr = wscale ? wscale + nb : nullptr;
+    // (int8: the scales are fp16, carried through the float pointer of the shared signature)
+    const float *wsr = !wscale ? nullptr : (wq ? reinterpret_cast<const float *>(reinterpret_cast<const half_t *>(wscale) + nb) : wscale + nb);
+    if (wq) {
+        if (wn == 4) {
+            if (epi) gemm256_launch_t<false, true, 4, 8>(x, Wr, yr, M, n, K, br, rr, nullptr, wsr, st, N);
+            else gemm256_launch_t<false, false, 4, 8>(x, Wr, yr, M, n, K, br, rr, nullptr, wsr, st, N);
+        } else {
+            if (epi) gemm256_launch_t<false, true, 2, 8>(x, Wr, yr, M, n, K, br, rr, nullptr, wsr, st, N);
+            else gemm256_launch_t<false, false, 2, 8>(x, Wr, yr, M, n, K, br, rr, nullptr, wsr, st, N);
+        }
+        return;
+    }
 #define LLMIE_G256(F8_, EPI_)                                                                                          \
     (wn == 4 ? gemm256_launch_t<F8_, EPI_, 4>(x, Wr, yr, M, n, K, br, rr, xscale, wsr, st, N)                          \
              : gemm256_launch_t<F8_, EPI_, 2>(x, Wr, yr, M, n, K, br, rr, xscale, wsr, st, N))
@@ -676,7 +721,7 @@ static void gemm256_range(bool fp8, int wn, const void *x, const void *W, half_t
 // (measured: 0.96 vs 1.12 PFLOP/s on full rounds).  A half-empty last round of 256-wide tiles (qkv at 2048 tokens: 384
 // tiles = 1.5 rounds) is avoided by running the full rounds 256-wide and the remaining columns 128-wide in a second launch.
 void gemm256_launch(bool fp8, const void *x, const void *W, half_t *y, int M, int N, int K, const half_t *bias,
-                    const half_t *residual, const float *xscale, const float *wscale, hipStream_t st) {
+                    const half_t *residual, const float *xscale, const float *wscale, hipStream_t st, int wq) {
     constexpr int cus = 256;
     constexpr bool no_split = false;
     const int tm = (M + 255) / 256, tn4 = (N + 255) / 256, tn2 = (N + 127) / 128;
@@ -704,11 +749,24 @@ void gemm256_launch(bool fp8, const void *x, const void *W, half_t *y, int M, in
     }
     if (plan == 42) {
         const int a_tn = (tiles4 / cus) * cus / tm;
-        gemm256_range(fp8, 4, x, W, y, M, N, K, bias, residual, xscale, wscale, st, 0, a_tn * 256);
-        gemm256_range(fp8, 2, x, W, y, M, N, K, bias, residual, xscale, wscale, st, a_tn * 256, N - a_tn * 256);
+        gemm256_range(fp8, 4, x, W, y, M, N, K, bias, residual, xscale, wscale, st, 0, a_tn * 256, wq);
+        gemm256_range(fp8, 2, x, W, y, M, N, K, bias, residual, xscale, wscale, st, a_tn * 256, N - a_tn * 256, wq);
     } else {
-        gemm256_range(fp8, plan, x, W, y, M, N, K, bias, residual, xscale, wscale, st, 0, N);
+        gemm256_range(fp8, plan, x, W, y, M, N, K, bias, residual, xscale, wscale, st, 0, N, wq);
     }
+}
+
+// int8 [N, K] weights through the eight-phase kernels (gemm8p.cuh, WQ = 8): prefill-sized M whose 256-row grid fills the chip
+bool g8p_w8_eligible(int M, int K, int N, const void *x, const void *wq, const void *scale, const void *y) {
+    return K % 64 == 0 && N % 4 == 0 && gemm256_fills(M, N) && (static_cast<size_t>(N) + 512) * K * 2 < (size_t{1} << 32) &&
+           (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wq)) % 16 == 0 &&
+           (reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(y)) % 8 == 0;
+}
+bool g8p_w8_swiglu_eligible(int M, int K, int two_inter, const void *x, const void *wq, const void *scale, const void *y) {
+    return K % 64 == 0 && two_inter % 8 == 0 && gemm256_swiglu_fills(M, two_inter) &&
+           (static_cast<size_t>(two_inter) + 512) * K * 2 < (size_t{1} << 32) &&
+           (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wq)) % 16 == 0 &&
+           (reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(y)) % 8 == 0;
 }
 
 int linear_f16_nk(const half_t *x, const half_t *W, half_t *y, int M, int K, int N, int epi,
@@ -767,7 +825,9 @@ extern "C" size_t llmie_linear_workspace_bytes(llmie_weight_format fmt, int M, i
         default: return 0;
     }
     if (fmt == LLMIE_W_F16 && M > 192) return 0;   // prefill-sized fp16: tiled kernels, no slabs
-    return linear_splitk_ws_floats(wbits, M, K, N) * sizeof(float);
+    // int8 / int4 at prefill-sized M: room for the fp16 image of W in front of the slabs (llmie_linear_w8a16 / _w4a16)
+    const size_t dq = (fmt == LLMIE_W_INT8 || fmt == LLMIE_W_INT4) ? ((linear_wq_dequant_bytes(wbits, M, K, N) + 255) & ~static_cast<size_t>(255)) : 0;
+    return dq + linear_splitk_ws_floats(wbits, M, K, N) * sizeof(float);
 }
 
 static bool slab_ws_of(void *workspace, size_t bytes, SlabWs *out) {

@@ -49,11 +49,21 @@ int linear_splitk(int wbits, const half_t *x, const void *W, const half_t *scale
                   const half_t *bias, const half_t *residual, SlabWs ws, hipStream_t st);
 // 256 x 256 LDS-DMA tiled GEMM (gemm256.cuh; K % 64 == 0 fp16, K % 128 == 0 fp8; 16-byte aligned operands); linear.hip
 bool gemm256_fills(int M, int N);
+// wq = 8: W is int8 [N, K] under fp16 activations and `wscale` carries its fp16 per-row scales (gemm8p.cuh, WQ = 8)
 void gemm256_launch(bool fp8, const void *x, const void *W, half_t *y, int M, int N, int K, const half_t *bias,
-                    const half_t *residual, const float *xscale, const float *wscale, hipStream_t st);
+                    const half_t *residual, const float *xscale, const float *wscale, hipStream_t st, int wq = 0);
 bool gemm256_swiglu_fills(int M, int two_inter);
 void gemm256_swiglu_launch(bool fp8, const void *x, const void *W, half_t *y, int M, int two_inter, int K, const float *xscale,
-                           const float *wscale, hipStream_t st);
+                           const float *wscale, hipStream_t st, int wq = 0);
+bool g8p_w8_eligible(int M, int K, int N, const void *x, const void *wq, const void *scale, const void *y);
+bool g8p_w8_swiglu_eligible(int M, int K, int two_inter, const void *x, const void *wq, const void *scale, const void *y);
+// fp16 image of int8 / int4 weights (row scales / group scales applied, one rounding): the operand of the prefill-sized
+// projections that have no in-kernel de-quantising form; quant_linear.hip
+int dequantize_weights_f16(int wbits, const void *wq, const half_t *scale, half_t *w16, int N, int K, int group, hipStream_t st);
+// rows from which a weight-only projection runs as an MFMA-bound tiled GEMM (prefill) instead of split-K passes
+constexpr int kWqPrefillRows = 192;
+// bytes of fp16 scratch linear_wq needs at M rows beside the split-K slabs (0: none)
+size_t linear_wq_dequant_bytes(int wbits, int M, int K, int N);
 // quantised-weight (int8 / int4) decode GEMV on the K-split kernel; defined in linear.hip
 struct GemvArgs;
 bool ksplit_eligible(int M, int K, int wbits);
@@ -67,9 +77,11 @@ int linear_fp8_gemv(const half_t *x, const uint8_t *wq, const float *wscale, hal
 int linear_fp8(const half_t *x, const uint8_t *w_fp8, const float *w_scale, half_t *y, int M, int K, int N, const half_t *bias,
                const half_t *residual, void *act_ws, size_t act_ws_bytes, SlabWs slabs, hipStream_t st);
 // weight-only int8/int4 linear with optional fused norm prologue / SwiGLU epilogue (quant_linear.hip)
+// M >= kWqPrefillRows (prefill): int8 through the eight-phase kernels' int8 form where eligible, else (and int4) a de-quantised
+// fp16 image in `deq` (linear_wq_dequant_bytes) + the fp16 GEMM; without `deq` those shapes keep the split-K passes
 int linear_wq(int wbits, const half_t *x, const void *wq, const half_t *scale, half_t *y, int M, int K, int N, int group,
               int epi, const half_t *bias, const half_t *residual, const half_t *gamma, const half_t *pre_bias, float eps,
-              SlabWs ws, hipStream_t st);
+              SlabWs ws, hipStream_t st, void *deq = nullptr, size_t deq_bytes = 0);
 
 // ---- packed-weight batch-decode projections (pk_gemm.cuh / pk_linear.hip): 1 <= M <= 32 rows on tile-packed weight images ----
 enum : int { PKF_F16 = 16, PKF_I8 = 8, PKF_I4 = 4, PKF_FP8 = 108 };                 // = PK_F16 ... of pk_gemm.cuh

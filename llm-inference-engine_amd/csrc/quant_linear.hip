@@ -136,12 +136,83 @@ __global__ __launch_bounds__(64) void quantize_w4_kernel(const half_t *__restric
     }
 }
 
+// fp16 image of quantised weights: w16[n, k] = fp16(code * scale) -- int8: code = the byte, scale[n]; int4: code = nibble - 8,
+// scale[n, k / group].  One thread per 8 weights (16 bytes out); the product of an integer below 2^7 and an fp16 scale is exact
+// in fp32 and rounded to fp16 once.
+template <int WBITS>
+__global__ __launch_bounds__(256) void dequant_f16_kernel(const unsigned char *__restrict__ wq, const half_t *__restrict__ scale,
+                                                          half_t *__restrict__ w16, size_t n8, int K, int group) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const size_t e0 = i * 8, row = e0 / K;
+    const int k = static_cast<int>(e0 - row * K);
+    half8_t o;
+    if constexpr (WBITS == 8) {
+        const float s = to_f32(scale[row]);
+        const uint2 v = *reinterpret_cast<const uint2 *>(wq + e0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int b = static_cast<int>(((j < 4 ? v.x : v.y) >> (8 * (j & 3))) & 0xffu);
+            o[j] = from_f32<half_t>(static_cast<float>(static_cast<int8_t>(b)) * s);
+        }
+    } else {
+        const float s = to_f32(scale[row * (K / group) + k / group]);
+        const unsigned v = *reinterpret_cast<const unsigned *>(wq + e0 / 2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = from_f32<half_t>(static_cast<float>(static_cast<int>((v >> (4 * j)) & 0xfu) - 8) * s);
+    }
+    *reinterpret_cast<half8_t *>(w16 + e0) = o;
+}
+
+int dequantize_weights_f16(int wbits, const void *wq, const half_t *scale, half_t *w16, int N, int K, int group, hipStream_t st) {
+    if ((wbits != 8 && wbits != 4) || K % 8 != 0 || (wbits == 4 && (group <= 0 || group % 8 != 0 || K % group != 0)) ||
+        (reinterpret_cast<uintptr_t>(wq) % 8) != 0 || (reinterpret_cast<uintptr_t>(w16) % 16) != 0) {
+        set_error("dequantize_weights: bits=%d K=%d group=%d not supported (K %% 8, group %% 8, aligned pointers)", wbits, K, group);
+        return LLMIE_ERR_UNSUPPORTED;
+    }
+    const size_t n8 = static_cast<size_t>(N) * K / 8;
+    const unsigned blocks = static_cast<unsigned>((n8 + 255) / 256);
+    if (wbits == 8) dequant_f16_kernel<8><<<blocks, 256, 0, st>>>(static_cast<const unsigned char *>(wq), scale, w16, n8, K, group);
+    else dequant_f16_kernel<4><<<blocks, 256, 0, st>>>(static_cast<const unsigned char *>(wq), scale, w16, n8, K, group);
+    return launch_status("dequantize_weights");
+}
+
+size_t linear_wq_dequant_bytes(int wbits, int M, int K, int N) {
+    if (M < kWqPrefillRows || (wbits != 8 && wbits != 4) || K % 8 != 0) return 0;
+    return static_cast<size_t>(N) * K * sizeof(half_t);
+}
+
 int linear_wq(int wbits, const half_t *x, const void *wq, const half_t *scale, half_t *y, int M, int K, int N, int group,
               int epi, const half_t *bias, const half_t *residual, const half_t *gamma, const half_t *pre_bias, float eps,
-              SlabWs ws, hipStream_t st) {
+              SlabWs ws, hipStream_t st, void *deq, size_t deq_bytes) {
     const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wq) |
                            reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(pre_bias)) % 16 == 0) &&
                          (static_cast<size_t>(K) * wbits / 8) % 16 == 0;
+    // ---- prefill-sized row counts: MFMA-bound, the weights are read M / 256 times from L2 instead of streamed once ----
+    if (M >= kWqPrefillRows && !gamma) {
+        // int8: the eight-phase GEMM takes the int8 rows as they are (raw bytes HBM -> LDS by DMA, de-quantised at fragment read,
+        // scale in the epilogue)
+        if (wbits == 8 && epi == EPI_SWIGLU && !bias && !residual && g8p_w8_swiglu_eligible(M, K, N, x, wq, scale, y)) {
+            gemm256_swiglu_launch(false, x, wq, y, M, N, K, nullptr, reinterpret_cast<const float *>(scale), st, 8);
+            return launch_status("linear_w8a16(gemm8p SwiGLU)");
+        }
+        if (wbits == 8 && epi == EPI_NONE && g8p_w8_eligible(M, K, N, x, wq, scale, y) &&
+            (reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) % 8 == 0) {
+            gemm256_launch(false, x, wq, y, M, N, K, bias, residual, nullptr, reinterpret_cast<const float *>(scale), st, 8);
+            return launch_status("linear_w8a16(gemm8p)");
+        }
+        // other shapes, and int4 (group scales along K): one pass writes the fp16 image of the matrix into the caller's scratch,
+        // the fp16 GEMM reads it back (mostly from the 256 MiB Infinity Cache): + (wbits / 8 + 2) bytes of traffic per weight
+        const size_t need = linear_wq_dequant_bytes(wbits, M, K, N);
+        if (deq && need && deq_bytes >= need && reinterpret_cast<uintptr_t>(deq) % 16 == 0 && reinterpret_cast<uintptr_t>(wq) % 8 == 0 &&
+            (wbits == 8 || (group % 8 == 0 && K % group == 0))) {
+            if (epi == EPI_SWIGLU && !gemm256_swiglu_fills(M, N)) goto no_prefill_form;   // (the fp16 GEMM has no fused SwiGLU there)
+            int rc = dequantize_weights_f16(wbits, wq, scale, static_cast<half_t *>(deq), N, K, group, st);
+            if (rc) return rc;
+            return linear_f16_nk(x, static_cast<const half_t *>(deq), y, M, K, N, epi, bias, residual, SlabWs{nullptr, 0}, st);
+        }
+    }
+no_prefill_form:
     if (aligned && ksplit_eligible(M, K, wbits)) {
         const GemvArgs a{x, wq, y, K, N, bias, residual, gamma, pre_bias, eps, epi, gamma ? 1 : 0, scale, group};
         if (gemv_q_launch(wbits, M, a, st)) return launch_status("linear_wq");
@@ -190,6 +261,14 @@ int linear_wq(int wbits, const half_t *x, const void *wq, const half_t *scale, h
         }
         return launch_status("linear_w8a16");
     }
+    // shapes none of the quantised kernels take (K not a multiple of their sub-blocks): the fp16 image, where the caller gave room
+    if (deq && K % 8 == 0 && deq_bytes >= static_cast<size_t>(N) * K * sizeof(half_t) && reinterpret_cast<uintptr_t>(deq) % 16 == 0 &&
+        reinterpret_cast<uintptr_t>(wq) % 8 == 0 && (wbits == 8 || (group % 8 == 0 && K % group == 0)) &&
+        (epi != EPI_SWIGLU || M <= 64 || gemm256_swiglu_fills(M, N))) {
+        int rc = dequantize_weights_f16(wbits, wq, scale, static_cast<half_t *>(deq), N, K, group, st);
+        if (rc) return rc;
+        return linear_f16_nk(x, static_cast<const half_t *>(deq), y, M, K, N, epi, bias, residual, SlabWs{nullptr, 0}, st);
+    }
     set_error("linear_wq: unsupported shape M=%d K=%d N=%d bits=%d without a split-K workspace (int8: M<=64, K%%64==0; int4: "
               "M<=8 on the GEMV path); size one with llmie_linear_workspace_bytes()", M, K, N, wbits);
     return LLMIE_ERR_UNSUPPORTED;
@@ -199,15 +278,31 @@ int linear_wq(int wbits, const half_t *x, const void *wq, const half_t *scale, h
 
 using namespace llmie;
 
+// [fp16 image | slabs] split of a caller workspace (a workspace too small for the image keeps the round-2 meaning: all slabs)
+struct WqWorkspace {
+    void *deq;
+    size_t deq_bytes;
+    SlabWs slabs;
+};
+static WqWorkspace wq_workspace(int wbits, int M, int K, int N, void *workspace, size_t workspace_bytes) {
+    const size_t dq = (linear_wq_dequant_bytes(wbits, M, K, N) + 255) & ~static_cast<size_t>(255);
+    if (workspace && dq && workspace_bytes >= dq) {
+        char *b = static_cast<char *>(workspace);
+        return WqWorkspace{b, dq, SlabWs{reinterpret_cast<float *>(b + dq), (workspace_bytes - dq) / sizeof(float)}};
+    }
+    return WqWorkspace{nullptr, 0, SlabWs{static_cast<float *>(workspace), workspace_bytes / sizeof(float)}};
+}
+
 extern "C" int llmie_linear_w8a16(const void *x, const int8_t *wq, const void *scale, void *y, int M, int K, int N,
                                   const void *bias, const void *residual, void *workspace, size_t workspace_bytes,
                                   llmie_stream stream) {
     LLMIE_REQUIRE(x && wq && scale && y, "linear_w8a16: NULL pointer");
     LLMIE_REQUIRE(M > 0 && K > 0 && N > 0, "linear_w8a16: bad shape");
     LLMIE_REQUIRE(reinterpret_cast<uintptr_t>(workspace) % 16 == 0, "linear_w8a16: workspace must be 16-byte aligned");
+    // workspace = [fp16 image of W (prefill-sized M without an in-kernel form) | split-K slabs], as llmie_linear_workspace_bytes sizes it
+    const WqWorkspace w = wq_workspace(8, M, K, N, workspace, workspace_bytes);
     return linear_wq(8, (const half_t *)x, wq, (const half_t *)scale, (half_t *)y, M, K, N, 0, EPI_NONE,
-                     (const half_t *)bias, (const half_t *)residual, nullptr, nullptr, 0.f,
-                     SlabWs{static_cast<float *>(workspace), workspace_bytes / sizeof(float)}, as_stream(stream));
+                     (const half_t *)bias, (const half_t *)residual, nullptr, nullptr, 0.f, w.slabs, as_stream(stream), w.deq, w.deq_bytes);
 }
 
 extern "C" int llmie_linear_w4a16(const void *x, const uint8_t *wq, const void *scale, void *y, int M, int K, int N,
@@ -217,9 +312,9 @@ extern "C" int llmie_linear_w4a16(const void *x, const uint8_t *wq, const void *
     LLMIE_REQUIRE(M > 0 && K > 0 && N > 0, "linear_w4a16: bad shape");
     LLMIE_REQUIRE(group > 0 && group % 32 == 0 && K % group == 0, "linear_w4a16: group must be a multiple of 32 dividing K");
     LLMIE_REQUIRE(reinterpret_cast<uintptr_t>(workspace) % 16 == 0, "linear_w4a16: workspace must be 16-byte aligned");
+    const WqWorkspace w = wq_workspace(4, M, K, N, workspace, workspace_bytes);
     return linear_wq(4, (const half_t *)x, wq, (const half_t *)scale, (half_t *)y, M, K, N, group, EPI_NONE,
-                     (const half_t *)bias, (const half_t *)residual, nullptr, nullptr, 0.f,
-                     SlabWs{static_cast<float *>(workspace), workspace_bytes / sizeof(float)}, as_stream(stream));
+                     (const half_t *)bias, (const half_t *)residual, nullptr, nullptr, 0.f, w.slabs, as_stream(stream), w.deq, w.deq_bytes);
 }
 
 extern "C" int llmie_quantize_w8(const void *w, int8_t *wq, void *scale, int N, int K, llmie_stream stream) {

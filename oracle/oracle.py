@@ -343,3 +343,64 @@ def context_decoder(cfg, layers, x, k_cache, v_cache, lens, hist):
         act = silu_and_mul(linear(hn2, w["gate_up"]).reshape(T, 2, I))
         h = add_residual(resid2, linear(act, w["down"]))
     return h
+
+
+def context_decoder_rows(cfg, w, x, k_cache, v_cache, lens, hist, rows, layer=0, kv_proj=None):
+    """ONE layer of context_decoder() evaluated for the packed-token rows `rows` only, so that a 7B-geometry layer at 2048 tokens
+    finishes in seconds on the host: K and V -- what every other token contributes to the sampled ones -- are computed for ALL
+    tokens and appended to the caches (in place, like context_decoder); Q, the attention rows, the output projection, the fused
+    residual norm and the FFN only for the sampled rows.  Same kernel oracles, same order (context_decoder.cpp:58-199,
+    context_attention.cpp:143-312, ffn.cpp:76-144); per output row the arithmetic is that of context_decoder().  Returns [len(rows), H].
+    kv_proj: the [T, 2 * kvh * hs] result of linear(rmsnorm(x), w["qkv"][H:]) from an earlier call on the same x and weights (the
+    K / V projection does not depend on how the tokens are cut into sequences), or a list that receives it."""
+    nh, kvh, hs, I = cfg["head_num"], cfg["kv_head_num"], cfg["head_size"], cfg["inter_size"]
+    eps = cfg.get("rms_eps", 1e-5)
+    lens, hist = _i(lens), _i(hist)
+    bs, T = lens.size, int(lens.sum())
+    mq = int(lens.max())
+    ctx = (lens + hist).astype(np.int32)
+    mk = int(ctx.max())
+    H = nh * hs
+    rows = np.asarray(rows, np.int64)
+    off, cum = cal_padding_offset(lens, mq, fill=0)
+    off = off.reshape(-1)[:T]
+    hn, resid = rmsnorm(x, w["attn_norm"], eps)
+    wqkv = _f(w["qkv"])
+    qkv = np.zeros((T, nh + 2 * kvh, hs), np.float32)
+    if isinstance(kv_proj, np.ndarray):
+        kvp = kv_proj
+    else:
+        kvp = linear(hn, wqkv[H:])          # K and V of every token
+        if isinstance(kv_proj, list):
+            kv_proj.append(kvp)
+    qkv[:, nh:] = kvp.reshape(T, 2 * kvh, hs)
+    qkv[rows, :nh] = linear(hn[rows], wqkv[:H]).reshape(len(rows), nh, hs)  # Q of the sampled tokens
+    bias = w.get("qkv_bias")
+    q, k, v = qkv_bias_transpose_rope(qkv, bias, off, hist, bs, mq, nh, kvh, hs, cfg.get("rotary_dim", hs),
+                                      cfg.get("rotary_base", 10000.0), fill=0.0)
+    concat_kv(k, k_cache, lens, hist, layer)
+    concat_kv(v, v_cache, lens, hist, layer)
+    kr, vr = repeat_kv(k_cache, ctx, layer, nh, mk), repeat_kv(v_cache, ctx, layer, nh, mk)
+    # the sampled queries of each sequence, packed to the front of a [bs, nh, R, hs] block; mask row = keys 0 .. history + position
+    seq = np.searchsorted(cum[1:], rows, side="right")
+    pos = rows - cum[seq]
+    per = [np.nonzero(seq == b)[0] for b in range(bs)]
+    R = max(1, max(len(p_) for p_ in per))
+    qs = np.zeros((bs, nh, R, hs), np.float32)
+    mask = np.zeros((bs, R, mk), np.float32)
+    mask[:, :, 0] = 1.0   # (padding rows of the block: one visible key, never read back)
+    for b in range(bs):
+        for j, i in enumerate(per[b]):
+            qs[b, :, j] = q[b, :, pos[i]]
+            mask[b, j, :] = 0.0
+            mask[b, j, :hist[b] + pos[i] + 1] = 1.0
+    p = scale_mask_softmax(batched_gemm(qs, kr, True), mask, 1.0 / np.sqrt(hs))
+    av = batched_gemm(p, vr, False)   # [bs, nh, R, hs]
+    att = np.empty((len(rows), H), np.float32)
+    for b in range(bs):
+        for j, i in enumerate(per[b]):
+            att[i] = av[b, :, j].reshape(H)
+    o = linear(att, w["o"])
+    hn2, resid2 = fused_add_bias_residual_rmsnorm(resid[rows], o, w.get("o_bias"), w["ffn_norm"], eps)
+    act = silu_and_mul(linear(hn2, w["gate_up"]).reshape(len(rows), 2, I))
+    return add_residual(resid2, linear(act, w["down"]))

@@ -33,8 +33,11 @@ def test_linear_workspace_query_follows_the_split_k_plans(llmie, lib):
     assert q(F16, 128, 4096, 12288) == 4 * 128 * 12288 * 4
     assert q(F16, 128, 4096, 4096) == 8 * 128 * 4096 * 4
     assert q(F16, 64, 4096, 22016) == 2 * 64 * 22016 * 4
-    # more than one pass of 128 rows reuses the same slabs
-    assert q(I8, 500, 4096, 4096) == q(I8, 128, 4096, 4096)
+    # more than one pass of 128 rows reuses the same slabs (below the prefill-sized forms: 192 rows)
+    assert q(I8, 191, 4096, 4096) == q(I8, 128, 4096, 4096)
+    # int8 / int4 from 192 rows (round 3): room for the fp16 image of W in front of the slabs
+    img = 4096 * 4096 * 2
+    assert q(I8, 500, 4096, 4096) == img + q(I8, 128, 4096, 4096) and q(I4, 192, 4096, 4096) == img + q(I4, 64, 4096, 4096)
     # garbage in, zero out
     assert q(F16, 0, 4096, 4096) == 0 and q(F16, 8, -1, 4096) == 0 and q(99, 8, 4096, 4096) == 0
 

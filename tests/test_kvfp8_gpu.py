@@ -81,11 +81,27 @@ def test_decode_with_fp8_kv_cache(llmie, name, nh, kvh, hs, I, L, bs, max_seq, s
     out = dec.forward(xd, torch.empty_like(xd), kd, vd, step)
     ocfg = dict(head_num=nh, kv_head_num=kvh, head_size=hs, inter_size=I, num_layers=L, vocab=100, max_seq_len=max_seq,
                 rotary_dim=hs, rotary_base=10000.0, rms_eps=1e-5)
-    exp = orc.self_decoder(ocfg, layers, x, kc, vc, step)  # appends the new (unquantised) rows into kc / vc
+    if L == 1:
+        # one layer: the oracle's kernels composed in numpy (self_decoder.cpp:69-119 order) with the device's treatment of the new
+        # token -- its k / v rows are quantised to the cache format BEFORE they are attended to -- so short contexts, where that one
+        # token carries real softmax weight, are held to the same bound
+        w = layers[0]
+        hn = _h(orc.rmsnorm(x, w["attn_norm"], 1e-5)[0])
+        qkv = _h(orc.rope_decode(_h(orc.linear(hn, w["qkv"])), nh, kvh, hs, step, hs, 10000.0))
+        ko, vo = nh * hs, (nh + kvh) * hs
+        qkv[:, ko:vo] = TAB[_to_e4m3(qkv[:, ko:vo] / KS)] * np.float32(KS)
+        qkv[:, vo:] = TAB[_to_e4m3(qkv[:, vo:] / VS)] * np.float32(VS)
+        mha = _h(orc.decoder_mha(qkv, None, kc, vc, 0, nh, kvh, hs, step))
+        h1 = _h(_h(orc.linear(mha.reshape(bs, H), w["o"])) + x)
+        h2 = _h(orc.rmsnorm(h1, w["ffn_norm"], 1e-5)[0])
+        act = _h(orc.silu_and_mul(orc.linear(h2, w["gate_up"]).reshape(bs, 2, I)))
+        exp = _h(orc.linear(act.reshape(bs, I), w["down"])) + h1
+    else:
+        exp = orc.self_decoder(ocfg, layers, x, kc, vc, step)  # appends the new (unquantised) rows into kc / vc
     got = out.float().cpu().numpy()
     err = np.abs(got - exp)
-    # the oracle attends to the new token's un-quantised k/v (1 of `step` tokens, hence the long contexts of the multi-layer
-    # cases): within the fp16 decoder tolerance
+    # (multi-layer cases: the oracle attends to the new token's un-quantised k/v, 1 of `step` tokens, hence their long contexts):
+    # within the fp16 decoder tolerance
     assert (err <= 3e-2 + 3e-2 * np.abs(exp)).all(), "max err %g (|exp| max %g)" % (err.max(), np.abs(exp).max())
     # appended rows: e4m3(new k / scale); layer 0 sees identical inputs -> codes equal up to rare rounding ties
     new_k = kd[0, :, :, step - 1].cpu().numpy()

@@ -72,6 +72,72 @@ def test_prefill_matches_oracle(llmie, name, nh, kvh, I, L, lens, hist):
     dec.close()
 
 
+def _quantise(w, fmt, group=128):
+    """numpy definition of the engine's quantisers (tests/test_quant_gpu.py checks the device quantisers against it bit for bit):
+    returns (codes, scales, de-quantised fp32 weights)"""
+    if fmt == "int8":
+        s = (np.abs(w).max(axis=1) / np.float32(127.0)).astype(np.float16)
+        s[s == 0] = np.float16(1.0)
+        q = np.clip(np.rint(w / s.astype(np.float32)[:, None]), -127, 127).astype(np.int8)
+        return q, s, q.astype(np.float32) * s.astype(np.float32)[:, None]
+    N, K = w.shape
+    wg = w.reshape(N, K // group, group)
+    s = (np.abs(wg).max(axis=2) / np.float32(7.0)).astype(np.float16)
+    s[s == 0] = np.float16(1.0)
+    q = np.clip(np.rint(wg / s.astype(np.float32)[:, :, None]), -8, 7).astype(np.int32)
+    deq = (q.astype(np.float32) * s.astype(np.float32)[:, :, None]).reshape(N, K)
+    q = q.reshape(N, K) + 8
+    return (q[:, 0::2] | (q[:, 1::2] << 4)).astype(np.uint8), s, deq
+
+
+QCASES = CASES + [("short_64", 8, 8, 1024, 2, [30, 34], [0, 7]), ("mid_150", 8, 8, 1024, 1, [150], [0])]
+
+
+@pytest.mark.parametrize("fmt", ["int8", "int4"])
+@pytest.mark.parametrize("name,nh,kvh,I,L,lens,hist", QCASES, ids=[c[0] for c in QCASES])
+def test_quantised_prefill_matches_oracle_on_dequantised_weights(llmie, fmt, name, nh, kvh, I, L, lens, hist):
+    """weight-only int8 / int4 engines (round 3): llmie_decoder_prefill on the quantised matrices against the oracle's context decoder
+    on the DE-QUANTISED weights -- the error left is the fp16 pipeline's, held to the fp16 prefill bounds (<= 64 / 128 tokens: fused
+    split-K form; up to 191: split-K passes; from 192: the prefill-sized forms of linear_wq)"""
+    rng = np.random.default_rng(43)
+    hs, max_seq = 128, 384
+    H, bs, T = nh * hs, len(lens), int(sum(lens))
+    if fmt == "int4":
+        I = I // 128 * 128   # group-128 scales along K: the down projection's K = I is a whole number of groups
+    layers = _model(rng, nh, kvh, hs, I, L, o_bias="bias" in name)
+    d = lambda a: None if a is None else torch.from_numpy(a).to(DEV)
+    eng, olayers = [], []
+    for w in layers:
+        e = dict(attn_norm=d(w["attn_norm"]).to(F16), ffn_norm=d(w["ffn_norm"]).to(F16))
+        o = dict(w)
+        for m in ("qkv", "o", "gate_up", "down"):
+            q, s, deq = _quantise(w[m], fmt)
+            e[m] = dict(data=d(q), scale=d(s))
+            o[m] = deq
+        e["o"]["bias"] = None if w["o_bias"] is None else d(w["o_bias"]).to(F16)
+        eng.append(e)
+        olayers.append(o)
+    cfg = dict(head_num=nh, kv_head_num=kvh, head_size=hs, inter_size=I, num_layers=L, vocab_size=100, max_seq_len=max_seq, max_batch=bs,
+               rotary_dim=hs, rotary_base=10000.0, rms_eps=1e-5, dtype=llmie.F16, wfmt=llmie.W_INT8 if fmt == "int8" else llmie.W_INT4,
+               int4_group=128)
+    dec = llmie.Decoder(cfg, eng)
+    x = _h(rng.standard_normal((T, H)).astype(np.float32))
+    kc = _h(rng.standard_normal((L, bs, kvh, max_seq, hs)).astype(np.float32) * 0.5)
+    vc = _h(rng.standard_normal((L, bs, kvh, max_seq, hs)).astype(np.float32) * 0.5)
+    kd, vd = torch.from_numpy(kc).to(DEV).to(F16), torch.from_numpy(vc).to(DEV).to(F16)
+    xd = torch.from_numpy(x).to(DEV).to(F16)
+    out = torch.empty_like(xd)
+    dec.prefill(xd, out, kd, vd, torch.tensor(lens, dtype=torch.int32, device=DEV), torch.tensor(hist, dtype=torch.int32, device=DEV), max(lens))
+    exp = oracle_prefill(olayers, x, kc, vc, np.array(lens, np.int32), np.array(hist, np.int32), nh, kvh, hs, I, max_seq)
+    got = out.float().cpu().numpy()
+    err = np.abs(got - exp)
+    assert (err <= 3e-2 + 3e-2 * np.abs(exp)).all(), "max err %g (|exp| max %g)" % (err.max(), np.abs(exp).max())
+    fro, proj = systematic_error(got, exp)
+    assert fro <= FRO_F16 and proj <= PROJ_F16, "relative Frobenius error %.3g, projection on the signal %.3g" % (fro, proj)
+    assert np.abs(kd.float().cpu().numpy() - kc).max() <= 2e-2
+    dec.close()
+
+
 def test_prefill_then_decode_consistency(llmie):
     rng = np.random.default_rng(42)
     nh, hs, I, L, max_seq, n = 8, 128, 1376, 2, 256, 150

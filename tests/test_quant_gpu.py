@@ -101,6 +101,56 @@ def test_linear_w8_fused_bias_residual(llmie):
     assert np.abs(y.float().cpu().numpy() - exp).max() <= 8e-3
 
 
+# prefill-sized M (round 3): int8 through the eight-phase GEMM's int8 B-operand form (gemm8p.cuh WQ = 8: plan "42" = 256-wide rounds +
+# 128-wide rest, plan 2 = 128-wide, ragged M / N edges, K = 11008), shapes whose grid does not fill the chip and all int4 shapes
+# through the fp16 image + fp16 GEMM.  Every output element against a plain torch fp32 GEMM over the de-quantised weights, and 96
+# sampled rows against the oracle (orc_linear_w8 / _w4).
+@pytest.mark.parametrize("bits,M,K,N", [(8, 2048, 4096, 12288), (8, 4000, 4096, 4096), (8, 2048, 11008, 4096), (8, 2048, 4096, 4100),
+                                        (8, 200, 4096, 1024), (8, 300, 512, 33000), (8, 512, 320, 24576), (8, 512, 64, 24576), (8, 2048, 192, 6144),
+                                        (4, 2048, 4096, 12288), (4, 4000, 11008, 4096),
+                                        (4, 250, 4096, 768)])
+def test_linear_wq_at_prefill_rows(llmie, bits, M, K, N):
+    rng = np.random.default_rng(36)
+    w = _h(rng.standard_normal((N, K)).astype(np.float32) / np.sqrt(K))
+    x = _h(rng.standard_normal((M, K)).astype(np.float32))
+    xd = torch.from_numpy(x).to(DEV).to(F16)
+    y = torch.full((M, N), 9.0, dtype=F16, device=DEV)
+    if bits == 8:
+        q, sc = _quant8_ref(w)
+        deq = q.astype(np.float32) * sc.astype(np.float32)[:, None]
+        llmie.linear_w8a16(xd, torch.from_numpy(q).to(DEV), torch.from_numpy(sc).to(DEV), y)
+    else:
+        q, sc = _quant4_ref(w, 128)
+        lo, hi = (q & 0xF).astype(np.float32) - 8, (q >> 4).astype(np.float32) - 8
+        vals = np.empty((N, K), np.float32)
+        vals[:, 0::2], vals[:, 1::2] = lo, hi
+        deq = vals * np.repeat(sc.astype(np.float32), 128, axis=1)
+        llmie.linear_w4a16(xd, torch.from_numpy(q).to(DEV), torch.from_numpy(sc).to(DEV), y, 128)
+    got = y.float()
+    ref = xd.float() @ torch.from_numpy(deq).to(DEV).t()
+    err = (got - ref).abs()
+    # int8: integer weights, fp32 accumulate, one scale, one rounding -> the fp16 kernel tolerance; int4 multiplies the fp16
+    # ROUNDING of code * scale (one more 2^-11 per weight, random): same bound
+    assert bool((err <= 2e-3 + 2e-3 * ref.abs()).all()), err.max().item()
+    rows = np.unique(np.minimum(np.concatenate([[0, 1, 15, 16, 127, 128, 255, 256, M - 2, M - 1], rng.choice(M, 86, replace=False)]), M - 1))
+    exp = orc.linear_w8(x[rows], q, sc.astype(np.float32)) if bits == 8 else orc.linear_w4(x[rows], q, sc.astype(np.float32), 128)
+    oerr = np.abs(got[torch.from_numpy(rows).to(DEV)].cpu().numpy() - exp)
+    assert (oerr <= 2e-3 + 2e-3 * np.abs(exp)).all(), oerr.max()
+
+
+def test_linear_w8_at_prefill_rows_fused_bias_residual(llmie):
+    rng = np.random.default_rng(37)
+    M, K, N = 2048, 4096, 4096
+    q, s = _quant8_ref(_h(rng.standard_normal((N, K)).astype(np.float32) / 64))
+    x, b, r = _h(rng.standard_normal((M, K)).astype(np.float32)), _h(rng.standard_normal(N).astype(np.float32)), \
+        _h(rng.standard_normal((M, N)).astype(np.float32))
+    xd, y = torch.from_numpy(x).to(DEV).to(F16), torch.from_numpy(r).to(DEV).to(F16)
+    llmie.linear_w8a16(xd, torch.from_numpy(q).to(DEV), torch.from_numpy(s).to(DEV), y, bias=torch.from_numpy(b).to(DEV).to(F16), residual=y)
+    deq = torch.from_numpy(q.astype(np.float32) * s.astype(np.float32)[:, None]).to(DEV)
+    ref = xd.float() @ deq.t() + torch.from_numpy(b).to(DEV)[None, :] + torch.from_numpy(r).to(DEV)
+    assert (y.float() - ref).abs().max().item() <= 8e-3
+
+
 @pytest.mark.parametrize("fmt,bs", [("int8", 1), ("int8", 4), ("int8", 9), ("int8", 20), ("int8", 32), ("int8", 72), ("int4", 1), ("int4", 2), ("int4", 6), ("int4", 19), ("int4", 40), ("int4", 70)])
 def test_quantised_decoder_matches_oracle_on_dequantised_weights(llmie, fmt, bs):
     rng = np.random.default_rng(35)
