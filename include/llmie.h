@@ -413,11 +413,22 @@ int llmie_lm_head_sample(llmie_decoder *dec, void *hidden /* [bs,H]; clobbered (
 enum {
     LLMIE_OP_ATTN_NORM = 0, LLMIE_OP_QKV_GEMM, LLMIE_OP_ROPE, LLMIE_OP_MHA, LLMIE_OP_O_GEMM,
     LLMIE_OP_FFN_NORM, LLMIE_OP_GATE_UP_SWIGLU, LLMIE_OP_DOWN_GEMM, LLMIE_OP_FINAL_NORM,
-    LLMIE_OP_LM_HEAD, LLMIE_OP_TOPK, LLMIE_OP_SAMPLING, LLMIE_OP_COUNT /* prefill re-uses the layer op kinds */
+    LLMIE_OP_LM_HEAD, LLMIE_OP_TOPK, LLMIE_OP_SAMPLING,
+    LLMIE_OP_CHAIN, /* ABI 3: one persistent launch = O -> gate/up -> down -> next QKV of the packed batch-decode path */
+    LLMIE_OP_COUNT /* prefill re-uses the layer op kinds */
 };
 int llmie_decoder_profile_begin(llmie_decoder *dec, int max_events);
 int llmie_decoder_profile_end(llmie_decoder *dec, llmie_stream stream, double *ms_by_op /*[LLMIE_OP_COUNT]*/,
                               int *launches_by_op /*[LLMIE_OP_COUNT]*/);
+
+/* ABI 3.  The persistent chain launches of the batch-decode path (4 < batch <= 32) synchronise their workgroups with in-kernel
+ * grid barriers whose spins are bounded: a barrier that expires (a workgroup was not resident) sets a device-side error word and
+ * the launch returns early instead of hanging.  This call synchronises `stream`, reads the word and returns LLMIE_ERR_LAUNCH with
+ * a message if it is set (and clears it); LLMIE_OK otherwise.  Not on the compute path: for tests and health checks. */
+int llmie_decoder_status(llmie_decoder *dec, llmie_stream stream);
+/* ABI 3, diagnostic: arm (device pointer to 256 x 16 uint64) or disarm (NULL) the phase-edge timestamps of the chain launches:
+ * per workgroup the s_memrealtime (100 MHz) values at kernel start, then before / behind every grid barrier, then at the end. */
+int llmie_decoder_debug_stamps(llmie_decoder *dec, void *stamps_dev);
 
 /* device-side helper for graph replay: *step_dev += 1 */
 int llmie_advance_step(int32_t *step_dev, llmie_stream stream);

@@ -95,6 +95,8 @@ _SIGS = {
     "llmie_kv_pages_copy": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "llmie_decoder_profile_begin": [_vp, _i],
     "llmie_decoder_profile_end": [_vp, _vp, _vp, _vp],
+    "llmie_decoder_status": [_vp, _vp],
+    "llmie_decoder_debug_stamps": [_vp, _vp],
     "llmie_abi_version": [],
     "llmie_last_error": [],
     "llmie_target_arch": [],
@@ -457,7 +459,7 @@ class Decoder:
                                           hidden.shape[0], step, _p(step_dev), end_id, _st()), "lm_head_sample")
 
     OPS = ("attn_norm", "qkv_gemm", "rope", "mha", "o_gemm", "ffn_norm", "gate_up_swiglu", "down_gemm",
-           "final_norm", "lm_head", "topk", "sampling")
+           "final_norm", "lm_head", "topk", "sampling", "chain")
 
     def profile_begin(self, max_events):
         _check(lib().llmie_decoder_profile_begin(self.handle, max_events), "decoder_profile_begin")
@@ -468,6 +470,14 @@ class Decoder:
         n = (C.c_int * len(self.OPS))()
         _check(lib().llmie_decoder_profile_end(self.handle, _st(), ms, n), "decoder_profile_end")
         return {op: (ms[i], n[i]) for i, op in enumerate(self.OPS)}
+
+    def debug_stamps(self, buf):
+        """diagnostic: chain launches write their phase-edge timestamps into buf (uint64 [256, 16] on the device); None disarms"""
+        _check(lib().llmie_decoder_debug_stamps(self.handle, _p(buf)), "decoder_debug_stamps")
+
+    def status(self):
+        """synchronises the current stream; raises if a grid barrier of a persistent chain launch timed out"""
+        _check(lib().llmie_decoder_status(self.handle, _st()), "decoder_status")
 
     def close(self):
         if self.handle:

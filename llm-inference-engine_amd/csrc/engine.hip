@@ -46,6 +46,9 @@ struct llmie_decoder {
     half_t *mhax = nullptr;                  // x32 image of the attention output [32, H]
     float *pk_slab = nullptr;
     size_t pk_slab_floats = 0;
+    // persistent chain launches of the packed path: one zeroed block of barrier counters per layer, one device error word
+    unsigned *pk_sync = nullptr, *pk_err = nullptr;
+    unsigned long long *pk_stamps = nullptr;   // diagnostic: phase-edge timestamps of the LAST chain launch of a step
     // paged KV cache of the current llmie_decoder_forward_paged call (null: dense caches)
     const int32_t *page_table = nullptr;
     int max_pages = 0, num_pages = 0;
@@ -141,7 +144,7 @@ static int packed_wf(const llmie_decoder_config *c) {
     return wf;
 }
 struct PackedCarve {
-    size_t per_layer[4], layer_bytes, hx, actx, mhax, slab, total;
+    size_t per_layer[4], layer_bytes, hx, actx, mhax, slab, sync, total;
 };
 static PackedCarve packed_carve(const llmie_decoder_config *c, int wf) {
     PackedCarve p{};
@@ -163,7 +166,8 @@ static PackedCarve packed_carve(const llmie_decoder_config *c, int wf) {
         sl = f > sl ? f : sl;
     }
     p.slab = align_up(sl * sizeof(float) + 16);
-    p.total = p.layer_bytes * c->num_layers + p.hx + p.actx + p.mhax + p.slab;
+    p.sync = align_up(static_cast<size_t>(c->num_layers) * pk_chain_sync_bytes()) + 256;   // barrier counters per layer + the error word
+    p.total = p.layer_bytes * c->num_layers + p.hx + p.actx + p.mhax + p.slab + p.sync;
     return p;
 }
 
@@ -311,7 +315,10 @@ extern "C" llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg, 
         d->mhax = reinterpret_cast<half_t *>(tail + pc.hx + pc.actx);
         d->pk_slab = reinterpret_cast<float *>(tail + pc.hx + pc.actx + pc.mhax);
         d->pk_slab_floats = (pc.slab - 16) / sizeof(float);
-        if (prc != LLMIE_OK || hipMemset(tail, 0, pc.hx + pc.actx + pc.mhax) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        d->pk_sync = reinterpret_cast<unsigned *>(tail + pc.hx + pc.actx + pc.mhax + pc.slab);
+        d->pk_err = reinterpret_cast<unsigned *>(tail + pc.hx + pc.actx + pc.mhax + pc.slab + pc.sync - 256);
+        if (prc != LLMIE_OK || hipMemset(tail, 0, pc.hx + pc.actx + pc.mhax) != hipSuccess || hipMemset(d->pk_sync, 0, pc.sync) != hipSuccess ||
+            hipDeviceSynchronize() != hipSuccess) {
             set_error("decoder_create: packing the weights for the batch path failed");
             delete d;
             return nullptr;
@@ -381,6 +388,36 @@ extern "C" int llmie_decoder_profile_end(llmie_decoder *dec, llmie_stream stream
         }
     }
     dec->ev_used = 0;
+    return LLMIE_OK;
+}
+
+extern "C" int llmie_decoder_status(llmie_decoder *dec, llmie_stream stream) {
+    LLMIE_REQUIRE(dec, "decoder_status: NULL decoder");
+    if (hipStreamSynchronize(as_stream(stream)) != hipSuccess) {
+        set_error("decoder_status: stream synchronise failed: %s", hipGetErrorString(hipGetLastError()));
+        return LLMIE_ERR_LAUNCH;
+    }
+    if (!dec->pk_err) return LLMIE_OK;
+    unsigned word = 0;
+    if (hipMemcpy(&word, dec->pk_err, sizeof(word), hipMemcpyDeviceToHost) != hipSuccess) {
+        set_error("decoder_status: reading the device error word failed");
+        return LLMIE_ERR_LAUNCH;
+    }
+    if (word) {
+        (void)hipMemset(dec->pk_err, 0, sizeof(word));
+        (void)hipMemset(dec->pk_sync, 0, static_cast<size_t>(dec->cfg.num_layers) * pk_chain_sync_bytes());   // counters are mid-flight: start over
+        set_error("decoder: a grid barrier of the persistent chain launch timed out (code 0x%08x, phase %u): not every workgroup was "
+                  "resident; set LLMIE_NO_CHAIN=1 to use the launch sequence", word, word & 0xfu);
+        return LLMIE_ERR_LAUNCH;
+    }
+    return LLMIE_OK;
+}
+
+// Diagnostic, not on the product path: the chain launches of this decoder write s_memrealtime (100 MHz) stamps of their phase
+// edges for every workgroup into `stamps_dev` ([256][16] uint64, device memory; every layer overwrites it); null disarms.
+extern "C" int llmie_decoder_debug_stamps(llmie_decoder *dec, void *stamps_dev) {
+    LLMIE_REQUIRE(dec, "decoder_debug_stamps: NULL decoder");
+    dec->pk_stamps = static_cast<unsigned long long *>(stamps_dev);
     return LLMIE_OK;
 }
 
@@ -540,6 +577,63 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
         const int wf = dec->pk_wf;
         half_t *hh = static_cast<half_t *>(h);
         half_t *qkvb = reinterpret_cast<half_t *>(dec->qkv);
+        // Round 3, OPT-IN (LLMIE_CHAIN=1): ONE persistent launch per layer for the chain O -> gate/up -> down (-> slab reduce) -> next
+        // layer's QKV (pk_gemm.cuh, pk_chain_kernel: grid barriers between the phases, the next phase's weight ring prefetched across
+        // each): 2 launches per layer (attention + chain) instead of 6, the launches' own code per phase (bit-identical outputs).
+        // Measured SLOWER than the launch sequence (int8, batch 32, MI355X: 94 us per chain against 78 us for the five launches it
+        // replaces; phase-edge timestamps, DESIGN.md section 9: a phase inside the chain takes what its launch takes -- the ~8 us of
+        // fixed cost per projection is the kernel's own prologue (activation slice, norm) and epilogue, not the launch -- and a grid
+        // barrier costs 5.5-7 us against ~2.5 us for a launch boundary), so the launch sequence stays the default.
+        static const int chain_off = getenv("LLMIE_CHAIN") ? 0 : 1;
+        bool chain = !chain_off && dec->pk_sync != nullptr;
+        if (chain) {
+            // probe: can every projection of a layer join a chain at this batch?  (pk_chain_add validates shapes / plans / LDS)
+            const llmie_layer_weights &w = dec->layers[0];
+            const llmie_decoder::PackedLayer &pw = dec->packed[0];
+            PkChain ch;
+            pk_chain_begin(&ch, wf, batch);
+            chain = ch.ok &&
+                    !pk_chain_add(&ch, 0, dec->mhax, pw.o, pw.sc[1] ? pw.sc[1] : w.o.scale, dec->hx, H, H, PKE_PLAIN, PKX_X | PKX_Y | PKX_RES, dec->hx, nullptr, nullptr, 0.f, nullptr, 0) &&
+                    !pk_chain_add(&ch, 1, dec->hx, pw.gate_up, pw.sc[2] ? pw.sc[2] : w.gate_up.scale, dec->actx, H, 2 * I, PKE_SWIGLU, PKX_X | PKX_Y, nullptr,
+                                  static_cast<const half_t *>(w.ffn_norm_gamma), static_cast<const half_t *>(w.o.bias), c.rms_eps, nullptr, 0) &&
+                    !pk_chain_add(&ch, 2, dec->actx, pw.down, pw.sc[3] ? pw.sc[3] : w.down.scale, dec->hx, I, H, PKE_PLAIN, PKX_X | PKX_RES | PKX_Y, dec->hx, nullptr, nullptr,
+                                  0.f, dec->pk_slab, dec->pk_slab_floats) &&
+                    (c.num_layers == 1 ||
+                     !pk_chain_add(&ch, 4, dec->hx, pw.qkv, pw.sc[0] ? pw.sc[0] : w.qkv.scale, qkvb, H, QKV, PKE_PLAIN, PKX_X, nullptr,
+                                   static_cast<const half_t *>(w.attn_norm_gamma), nullptr, c.rms_eps, nullptr, 0));
+        }
+        if (chain) {
+            for (int l = 0; l < c.num_layers; ++l) {
+                const llmie_layer_weights &w = dec->layers[l];
+                const llmie_decoder::PackedLayer &pw = dec->packed[l];
+                const bool first = l == 0, last = l + 1 == c.num_layers;
+                if (first)
+                    TIMED(LLMIE_OP_QKV_GEMM, pk_linear(wf, hh, pw.qkv, pw.sc[0] ? pw.sc[0] : w.qkv.scale, qkvb, batch, H, QKV, PKE_PLAIN, 0, nullptr,
+                                                       static_cast<const half_t *>(w.attn_norm_gamma), nullptr, c.rms_eps, nullptr, 0, st));
+                TIMED(LLMIE_OP_MHA, decoder_mha_rope(dec->qkv, w.qkv.bias, k_cache, v_cache, dec->mhax, l, batch, c.head_num, c.kv_head_num,
+                                                     c.head_size, c.max_seq_len, step, step_dev, dec->attn_ws, dec->attn_ws_bytes,
+                                                     dec->rope_table, c.rotary_dim, nullptr, dt, st, nullptr, nullptr, kv8, k_scale, v_scale,
+                                                     dec->page_table, dec->max_pages, dec->num_pages, dec->ragged, 1));
+                PkChain ch;
+                pk_chain_begin(&ch, wf, batch);
+                rc = pk_chain_add(&ch, 0, dec->mhax, pw.o, pw.sc[1] ? pw.sc[1] : w.o.scale, dec->hx, H, H, PKE_PLAIN, PKX_X | PKX_Y | (first ? 0 : PKX_RES),
+                                  first ? hh : dec->hx, nullptr, nullptr, 0.f, nullptr, 0);
+                if (!rc) rc = pk_chain_add(&ch, 1, dec->hx, pw.gate_up, pw.sc[2] ? pw.sc[2] : w.gate_up.scale, dec->actx, H, 2 * I, PKE_SWIGLU, PKX_X | PKX_Y, nullptr,
+                                           static_cast<const half_t *>(w.ffn_norm_gamma), static_cast<const half_t *>(w.o.bias), c.rms_eps, nullptr, 0);
+                if (!rc) rc = pk_chain_add(&ch, 2, dec->actx, pw.down, pw.sc[3] ? pw.sc[3] : w.down.scale, last ? hh : dec->hx, I, H, PKE_PLAIN,
+                                           PKX_X | PKX_RES | (last ? 0 : PKX_Y), dec->hx, nullptr, nullptr, 0.f, dec->pk_slab, dec->pk_slab_floats);
+                if (!rc && !last) {
+                    const llmie_layer_weights &wn = dec->layers[l + 1];
+                    const llmie_decoder::PackedLayer &pn = dec->packed[l + 1];
+                    rc = pk_chain_add(&ch, 4, dec->hx, pn.qkv, pn.sc[0] ? pn.sc[0] : wn.qkv.scale, qkvb, H, QKV, PKE_PLAIN, PKX_X, nullptr,
+                                      static_cast<const half_t *>(wn.attn_norm_gamma), nullptr, c.rms_eps, nullptr, 0);
+                }
+                if (rc) return rc;
+                ch.stamps = dec->pk_stamps;   // (diagnostic; null unless llmie_decoder_debug_stamps armed it)
+                TIMED(LLMIE_OP_CHAIN, pk_chain_launch(&ch, dec->pk_sync + static_cast<size_t>(l) * (pk_chain_sync_bytes() / sizeof(unsigned)), dec->pk_err, st));
+            }
+            return LLMIE_OK;
+        }
         for (int l = 0; l < c.num_layers; ++l) {
             const llmie_layer_weights &w = dec->layers[l];
             const llmie_decoder::PackedLayer &pw = dec->packed[l];

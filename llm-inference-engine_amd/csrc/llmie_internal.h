@@ -96,6 +96,21 @@ int pk_linear(int wf, const half_t *x, const void *Wp, const void *scale, half_t
               const half_t *residual, const half_t *gamma, const half_t *pre_bias, float eps, float *slab_ws, size_t slab_ws_floats,
               hipStream_t st);
 int x32_convert(const half_t *src, half_t *dst, int M, int K, int to_x32, hipStream_t st);
+// Persistent chain (pk_chain_kernel): up to 5 dependent phases -- each a pk_linear of the same format and row count whose x is an
+// x32 image -- in ONE launch with grid barriers in between and the next phase's weight ring prefetched across each barrier.
+// `sync`: pk_chain_sync_bytes() ZEROED bytes of this launch; `err`: the owner's device error word (non-zero after a barrier
+// timed out).  A failed pk_chain_add leaves the chain unusable (the caller falls back to the launch sequence).
+struct PkChain {
+    int wf, M, nph, lds;
+    bool ok;
+    unsigned long long *stamps;   // diagnostic: device buffer [256][16] of phase-edge timestamps (null: none)
+    alignas(16) unsigned char args[1024];
+};
+void pk_chain_begin(PkChain *ch, int wf, int M);
+int pk_chain_add(PkChain *ch, int slot /* 0 = O, 1 = gate/up, 2 = down, 4 = next QKV */, const half_t *x, const void *Wp, const void *scale, half_t *y, int K, int N, int epi, int x32_flags,
+                 const half_t *residual, const half_t *gamma, const half_t *pre_bias, float eps, float *slab_ws, size_t slab_ws_floats);
+int pk_chain_launch(PkChain *ch, unsigned *sync, unsigned *err, hipStream_t st);
+size_t pk_chain_sync_bytes();
 
 // decode attention with optional RoPE (rope may be null) fused in front (rope = [max_pos][head_size/2] (cos,sin) table); attention_decode.hip
 int decoder_mha_rope(const void *qkv, const void *qkv_bias, void *k_cache, void *v_cache, void *out, int layer, int batch,

@@ -186,9 +186,81 @@ __host__ __device__ constexpr PkLds pk_lds(int mt, int epi, int norm_halves /* s
     return PkLds{red, ring, etab, rtab, red + ring + etab + rtab + stat};
 }
 
+// A value every lane holds identically, moved into scalar registers (the chain kernel reads its phase descriptors through a
+// run-time index: hipcc then keeps them in VGPRs, and the "s" operands of the asm loads need SGPRs)
+__device__ __forceinline__ int pk_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T> __device__ __forceinline__ T *pk_uni(T *p) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(u)));
+    const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(u >> 32)));
+    return reinterpret_cast<T *>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+__device__ __forceinline__ PkArgs pk_uni(const PkArgs &a) {
+    PkArgs u;
+    u.x = pk_uni(a.x); u.Wp = pk_uni(a.Wp);
+    u.M = pk_uni(a.M); u.K = pk_uni(a.K); u.N = pk_uni(a.N); u.units = pk_uni(a.units); u.nblk = pk_uni(a.nblk); u.bps = pk_uni(a.bps);
+    u.y = pk_uni(a.y); u.slab = pk_uni(a.slab); u.scale = pk_uni(a.scale); u.residual = pk_uni(a.residual);
+    u.x_x32 = pk_uni(a.x_x32); u.y_x32 = pk_uni(a.y_x32); u.res_x32 = pk_uni(a.res_x32);
+    u.gamma = pk_uni(a.gamma); u.pre_bias = pk_uni(a.pre_bias);
+    u.eps = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.eps)));
+    return u;
+}
+
+// This wave's weight stream of one projection: the running DMA source pointer over (unit, tile, block) and the ring fill.  A
+// struct of its own because the persistent chain kernel (pk_chain_kernel below) starts the NEXT projection's stream -- its first
+// D ring elements -- before the grid barrier that ends the current one: the addresses of a weight stream depend on nothing a
+// previous phase computes.
+template <int WF> struct PkStream {
+    static constexpr bool I4 = WF == PK_I4;
+    const unsigned char *src, *ssrc;
+    long step_in, step_unit, sstep_in, sstep_unit;
+    int ri, ru, ept, T, tpi;
+    // bx / by / gx: the workgroup's coordinates in the launch plan of this projection (gx workgroups along N, slice by of K)
+    __device__ __forceinline__ void init(const PkArgs &a, const int tpi_, const int bx, const int by, const int gx, const int wave) {
+        constexpr int NW = 8;
+        tpi = tpi_;
+        const int nb0 = by * a.bps, nb1 = min(a.nblk, nb0 + a.bps), nbs = nb1 - nb0;
+        const int per = nbs / NW, rem = nbs - per * NW;
+        const int cnt = per + (wave < rem ? 1 : 0);
+        const int blk0 = nb0 + wave * per + min(wave, rem);
+        const int iters = bx < a.units ? (a.units - bx + gx - 1) / gx : 0;
+        ept = cnt > 0 ? cnt + (I4 ? 1 : 0) : 0;
+        T = iters * tpi * ept;
+        const size_t tile_bytes = static_cast<size_t>(a.nblk) * 1024;
+        step_in = static_cast<long>(tile_bytes) - static_cast<long>(cnt) * 1024;
+        step_unit = static_cast<long>(static_cast<size_t>(gx) * tpi - (tpi - 1)) * static_cast<long>(tile_bytes) - static_cast<long>(cnt) * 1024;
+        src = a.Wp + (static_cast<size_t>(bx) * tpi * a.nblk + blk0) * 1024;
+        ssrc = I4 ? reinterpret_cast<const unsigned char *>(a.scale) + (static_cast<size_t>(bx) * tpi * a.nblk + blk0) * 32 : nullptr;
+        sstep_in = static_cast<long>(a.nblk) * 32;
+        sstep_unit = static_cast<long>(static_cast<size_t>(gx) * tpi - (tpi - 1)) * static_cast<long>(a.nblk) * 32;
+        ri = 0;
+        ru = 0;
+    }
+    // the next stream element -> ring slot `slot_bytes` (ISSUE = false: only step the pointers, for elements a previous phase fetched)
+    template <bool ISSUE = true> __device__ __forceinline__ void next(const unsigned ring_lds, const unsigned slot_bytes, const int lane) {
+        if (I4 && ru == 0) {
+            if constexpr (ISSUE) pk_dma4(lane * 4, pk_uni(ssrc), pk_uni(static_cast<int>(ring_lds + slot_bytes)));
+        } else {
+            if constexpr (ISSUE) pk_dma16_nt(lane * 16, pk_uni(src), pk_uni(static_cast<int>(ring_lds + slot_bytes)));
+            src += 1024;
+        }
+        if (++ru == ept) {
+            ru = 0;
+            ++ri;
+            src += (tpi == 2 && (ri & 1)) ? step_in : step_unit;
+            if constexpr (I4) ssrc += (tpi == 2 && (ri & 1)) ? sstep_in : sstep_unit;
+        }
+    }
+};
+
+// One projection on the workgroup (bx, by) of a plan with gx workgroups along N.  `prefetched`: the first D elements of this
+// wave's stream are already in (or on their way into) its ring -- issued by the previous phase of a chain launch.
 // XM (activation layout, a compile-time fact of the launch): 0 = row-major x; 1 = x32 image
-template <int MT, int WF, int EPI, int XM>
-__global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
+// `next_fill(ring_lds, wave, lane)`: called once per wave when its own stream has left the ring (the chain kernel issues the next
+// projection's first D elements there; the single-projection kernel passes a no-op)
+template <int MT, int WF, int EPI, int XM, typename NextFill>
+__device__ __forceinline__ void pk_phase(const PkArgs &a, const int bx, const int by, const int gx, unsigned char *pk_smem, const bool prefetched,
+                                         NextFill &&next_fill) {
     constexpr bool XL = XM != 0;
     using F = PkFmt<WF>;
     constexpr int NW = 8, KB = F::KB, SPB = F::SPB, XBLK = F::XBLK;
@@ -199,11 +271,9 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
     constexpr int D = pk_ring_depth(EPI);
     constexpr int XPB = SPB * MT;                        // activation fragments (= loads) per block
     typedef __attribute__((address_space(3))) void *lptr_t;
-    extern __shared__ __attribute__((aligned(16))) unsigned char pk_smem[];
     const bool has_res = EPI == PK_EPI_PLAIN && a.residual != nullptr;
     const PkLds lay = pk_lds(MT, EPI, a.gamma ? (a.pre_bias ? 2 * a.K : a.K) : 0, has_res);
     floatx4 *red = reinterpret_cast<floatx4 *>(pk_smem);                                  // [NPAR][NW][TPI * MT][64]
-    unsigned char *ring_all = pk_smem + lay.red;
     float *etab = reinterpret_cast<float *>(pk_smem + lay.red + lay.ring);               // [units][TPI][16] row scales
     half_t *rtab = reinterpret_cast<half_t *>(pk_smem + lay.red + lay.ring + lay.etab);  // [units][MT * 16][16] residual pieces
     float *stat = reinterpret_cast<float *>(pk_smem + lay.red + lay.ring + lay.etab + lay.rtab);   // [2][NW][MT][16] sum of squares | amax
@@ -213,17 +283,25 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: K range, block addresses stay scalar
     const int r = lane & 15, q = lane >> 4;
     // ---- this wave's K range: blocks [blk0, blk0 + cnt) of slice blockIdx.y ----
-    const int nb0 = blockIdx.y * a.bps, nb1 = min(a.nblk, nb0 + a.bps), nbs = nb1 - nb0;
+    const int nb0 = by * a.bps, nb1 = min(a.nblk, nb0 + a.bps), nbs = nb1 - nb0;
     const int per = nbs / NW, rem = nbs - per * NW;
     const int cnt = per + (wave < rem ? 1 : 0);                  // 0 <= cnt <= XBLK
     const int blk0 = nb0 + wave * per + min(wave, rem);
     auto blkc = [&](int u) { return min(blk0 + u, nb1 - 1); };   // in-bounds address for a slot the wave does not own (zero x)
 
     // ---- work units of this workgroup: blockIdx.x, + gridDim.x, ... ; its tile stream has L = iters * TPI elements ----
-    if (static_cast<int>(blockIdx.x) >= a.units) return;
-    const int iters = (a.units - static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
+    unsigned char *ring_all = pk_smem + lay.red;
+    unsigned char *ring = ring_all + wave * (pk_ring_depth(EPI) * 1024);
+    const unsigned ring_lds = static_cast<unsigned>(reinterpret_cast<size_t>((lptr_t)ring));   // LDS byte address, wave-uniform
+    // the next projection's ring fill (chain launch): issued when this wave's own stream has left the ring
+    auto prefetch_next = [&]() { next_fill(ring_lds, wave, lane); };
+    if (bx >= a.units) {   // no work unit of this projection for this workgroup (it still takes part in what follows the phase)
+        prefetch_next();
+        return;
+    }
+    const int iters = (a.units - bx + gx - 1) / gx;
     const int L = iters * TPI;
-    auto unit_at = [&](int it) { return it * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x); };
+    auto unit_at = [&](int it) { return it * gx + bx; };
     // this wave's block stream: element k = (tile i = k / ept, block u = k % ept), T = L * ept elements.
     // int4 (group-128 scales, KB = 128 = one group per block): every tile's blocks are preceded by ONE more stream element, the
     // [blocks][16 rows] fp16 scale records of the wave's slice (<= 4 x 32 bytes, fetched as a 256-byte DMA into a ring slot of
@@ -232,35 +310,14 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
     constexpr int SE = I4 ? 1 : 0;
     const int ept = cnt > 0 ? cnt + SE : 0;
     const int T = L * ept;
-    unsigned char *ring = ring_all + wave * (D * 1024);
     const unsigned woff = lane * 16;
-    const unsigned ring_lds = static_cast<unsigned>(reinterpret_cast<size_t>((lptr_t)ring));   // LDS byte address, wave-uniform
     // DMA source of the NEXT stream element to fetch: a running scalar pointer (no multiplications in the loop).  Inside a
     // tile the wave's blocks are contiguous KiB; from its last block the pointer steps to the wave's first block of the next
-    // tile of the unit, or of the workgroup's next unit.
-    const size_t tile_bytes = static_cast<size_t>(a.nblk) * 1024;
-    const long step_in = static_cast<long>(tile_bytes) - static_cast<long>(cnt) * 1024;
-    const long step_unit = static_cast<long>(static_cast<size_t>(gridDim.x) * TPI - (TPI - 1)) * static_cast<long>(tile_bytes) - static_cast<long>(cnt) * 1024;
-    const unsigned char *src = a.Wp + (static_cast<size_t>(unit_at(0)) * TPI * a.nblk + blk0) * 1024;
-    // int4: the scale image [tiles][nblk][16] fp16 runs beside the weight image (a.scale), 32 bytes per block
-    const unsigned char *ssrc = I4 ? reinterpret_cast<const unsigned char *>(a.scale) + (static_cast<size_t>(unit_at(0)) * TPI * a.nblk + blk0) * 32 : nullptr;
-    const long sstep_in = static_cast<long>(a.nblk) * 32;
-    const long sstep_unit = static_cast<long>(static_cast<size_t>(gridDim.x) * TPI - (TPI - 1)) * static_cast<long>(a.nblk) * 32;
-    int ri = 0, ru = 0;   // (tile, element inside the tile) of the next stream element to fetch
-    auto dma_next = [&](const unsigned slot_bytes) {
-        if (I4 && ru == 0) {
-            pk_dma4(lane * 4, ssrc, ring_lds + slot_bytes);
-        } else {
-            pk_dma16_nt(woff, src, ring_lds + slot_bytes);
-            src += 1024;
-        }
-        if (++ru == ept) {
-            ru = 0;
-            ++ri;
-            src += (TPI == 2 && (ri & 1)) ? step_in : step_unit;
-            if constexpr (I4) ssrc += (TPI == 2 && (ri & 1)) ? sstep_in : sstep_unit;
-        }
-    };
+    // tile of the unit, or of the workgroup's next unit.  (int4: the scale image [tiles][nblk][16] fp16 runs beside the weight
+    // image, a.scale, 32 bytes per block.)
+    PkStream<WF> strm;
+    strm.init(a, TPI, bx, by, gx, wave);
+    auto dma_next = [&](const unsigned slot_bytes) { strm.next(ring_lds, slot_bytes, lane); };
 
     PK_STAMP(0);
     // ================= issue phase: every asm load of the kernel except the ring refills, oldest first =================
@@ -316,7 +373,11 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
     }
     PK_STAMP(8);
     // (2) the ring fill: the first D blocks of the wave's weight stream
-    for (int k = 0; k < D && k < T; ++k) dma_next(k * 1024);
+    if (prefetched) {
+        for (int k = 0; k < D && k < T; ++k) strm.template next<false>(ring_lds, k * 1024, lane);
+    } else {
+        for (int k = 0; k < D && k < T; ++k) dma_next(k * 1024);
+    }
     // (3) the activation slice of this wave = rows [0, 16 MT) x its XBLK blocks, XBLK * XPB loads in block order.
     // B fragments: lane (c = r, q) holds x[16 t + c][k .. k + 8), k = blk * KB + 32 s + 8 q; one register array from the load to
     // the MFMA operand (zeroing, bias, gamma in place).
@@ -579,7 +640,7 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
                     for (int e = 0; e < 4; ++e) v[0][e] *= xs;
                 }
                 if (m < a.M && n0 < a.N)
-                    *reinterpret_cast<floatx4 *>(a.slab + (static_cast<size_t>(blockIdx.y) * a.M + m) * a.N + n0) = v[0];
+                    *reinterpret_cast<floatx4 *>(a.slab + (static_cast<size_t>(by) * a.M + m) * a.N + n0) = v[0];
             } else if constexpr (EPI == PK_EPI_SWIGLU) {
                 const int inter = a.N >> 1;
                 floatx4 sg{1.f, 1.f, 1.f, 1.f}, su{1.f, 1.f, 1.f, 1.f};
@@ -770,6 +831,9 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
 #pragma unroll
         for (int t = 0; t < MT; ++t) acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
         tile_blocks();
+        // every element of this wave's stream has been read out of the ring: the next projection's first D elements go in, and
+        // stream from HBM under the last reduction, the epilogue stores, the grid barrier and the next prologue
+        if (i == L - 1) prefetch_next();
         if (i == 0) {
             PK_STAMP(5);
             norm_finalize();
@@ -782,6 +846,187 @@ __global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
         if (i == 0) PK_STAMP(6);
     }
     PK_STAMP(7);
+}
+
+template <int MT, int WF, int EPI, int XM>
+__global__ __launch_bounds__(512, 2) void pk_mfma_kernel(const PkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pk_smem_dyn[];
+    pk_phase<MT, WF, EPI, XM>(a, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), static_cast<int>(gridDim.x), pk_smem_dyn, false,
+                              [](unsigned, int, int) {});
+}
+
+// ================= persistent chain: several dependent projections of a decoder layer in ONE launch =================
+// Batch decode (4 < batch <= 32) is a chain of weight-streaming projections, each of which needs ALL of its predecessor's output
+// (self_decoder.cpp:69-119: attention -> O -> norm -> gate/up -> SwiGLU -> down -> next layer's norm -> QKV).  As separate launches
+// every link pays ~7 us that are not streaming (launch ramp, first-byte latency, the activation slice through the CU's address
+// path, drain) against 3-15 us of stream; here the links O -> gate/up -> down (-> slab reduce) -> next QKV run as phases of one
+// launch on one workgroup per CU, separated by grid barriers, and -- what makes the barrier cheaper than the launch it replaces --
+// every wave issues the NEXT phase's first D ring elements (12 KiB per wave, 96 KiB per CU, 24 MiB chip-wide) as soon as its own
+// stream has left the ring: the HBM stream runs through the last reduction, the barrier and the next prologue's activation loads.
+// Phases use pk_phase unchanged (same arithmetic, same order: results are bit-identical to the launch sequence).
+//
+// Grid barrier (MI355X guide, "barrier-xcd" form without the placement assumption): workgroups arrive in groups of 32 on a counter
+// of their group (one 128-byte line each), the last of a group on the top counter, the last of all stores the epoch into every
+// group's generation word, which the group's workgroups poll (relaxed agent-scope loads, s_sleep between polls).  Producer side:
+// every wave drains its stores, workgroup barrier, one lane's agent-scope release + drained wait, then the arrive; consumer
+// side: one agent-scope acquire + wait behind the poll, workgroup barrier, then plain loads.  Counters are monotonic inside a
+// launch and start from zero: the LAST workgroup to leave the kernel (a `done` counter every workgroup adds to behind its last
+// barrier) zeroes the block again, so a replayed hipGraph needs no memset node (measured: a captured hipMemsetAsync in front of the
+// step did not re-zero the counters on the second replay -- barriers fell through, wrong results, no timeout); the owner zeroes
+// the block once at create and after a reported error.  Every spin is bounded: on expiry
+// the lane sets the decoder's error word and the workgroup leaves the kernel (later barriers see the word and leave at once), so
+// a residency mistake fails llmie_decoder_status() in a test instead of hanging the GPU.
+constexpr int PK_SYNC_WORDS = (8 + 1 + 8 + 1) * 32;   // arrive[8] | top | gen[8] | done, one 128-byte line each
+constexpr int PK_CHAIN_MAX_PHASES = 5;
+enum : int { PK_PH_NONE = -1, PK_PH_PLAIN = 0, PK_PH_SWIGLU = 1, PK_PH_SLAB = 2, PK_PH_REDUCE = 3 };
+struct PkChainPhase {
+    PkArgs a;        // REDUCE: M, N, slab, scale (row scales or null), residual, y, res_x32, y_x32 are used
+    int kind;        // PK_PH_*
+    int gx, ks;      // launch plan of the projection: gx workgroups along N x ks slices of K (workgroup w -> (w % gx, w / gx))
+    int scale_f32;   // REDUCE: a.scale holds fp32 row scales (e4m3 weights) instead of fp16 ones
+};
+struct PkChainArgs {
+    PkChainPhase ph[PK_CHAIN_MAX_PHASES];   // fixed slots, see pk_chain_kernel
+    int nph;
+    unsigned *sync;   // PK_SYNC_WORDS zeroed words of this launch
+    unsigned *err;    // the decoder's device error word (0 = fine)
+    unsigned long long *stamps;   // diagnostic (null in the product path): [256 workgroups][16] s_memrealtime values at the phase edges
+    int flag_off;     // byte offset, inside the dynamic LDS, of the barrier's broadcast word (behind every phase's carve; no static
+                      // __shared__ object: one would shift the 16-byte alignment of the dynamic region)
+};
+
+typedef __attribute__((address_space(1))) unsigned pk_gu32;
+__device__ __forceinline__ bool pk_grid_barrier(unsigned *sync, unsigned *err, const unsigned epoch, const int wg, const int nwg, volatile int *bar_ok) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its stores (and ring prefetch) are out
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        pk_gu32 *arrive = (pk_gu32 *)sync, *top = (pk_gu32 *)(sync + 8 * 32), *gen = (pk_gu32 *)(sync + 9 * 32), *e = (pk_gu32 *)err;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the compiler may drop the fence's own wait: keep this one)
+        const int g = wg >> 5, ng = (nwg + 31) >> 5, gsize = min(32, nwg - (g << 5));
+        bool ok = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+        if (ok) {
+            const unsigned old = __hip_atomic_fetch_add(arrive + g * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == static_cast<unsigned>(gsize) * epoch - 1u) {
+                const unsigned t = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t == static_cast<unsigned>(ng) * epoch - 1u)
+                    for (int i = 0; i < ng; ++i) __hip_atomic_store(gen + i * 32, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+            while (__hip_atomic_load(gen + g * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+                __builtin_amdgcn_s_sleep(2);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull) {   // 1 s: some workgroup is not resident / never arrived
+                    __hip_atomic_store(e, 0xBA221E20u + epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = false;
+                    break;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *bar_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    return *bar_ok != 0;
+}
+
+// Fixed slot layout (compile-time slot indices keep every descriptor field a plain kernel-argument load, re-readable anywhere,
+// instead of ~30 scalar registers held for a whole phase -- with a run-time slot index the 32-row int8 / int4 forms spilled):
+//   slot 0 PLAIN (O)  |  1 SWIGLU (gate/up)  |  2 SLAB or PLAIN (down)  |  3 REDUCE (behind a SLAB)  |  4 PLAIN (next layer's QKV)
+// kind PK_PH_NONE = slot not used (the chain then ends / starts elsewhere); a barrier follows a slot when a later one is used.
+template <int MT, int WF, int SLOT, int EPI, int NEXT>
+__device__ __forceinline__ void pk_chain_slot(const PkChainArgs &c, unsigned char *smem, const int wg, const bool prefetched) {
+    const int gx = c.ph[SLOT].gx;
+    const int by = wg / gx;
+    const int bx = by < c.ph[SLOT].ks ? wg - by * gx : c.ph[SLOT].a.units;   // workgroups beyond the plan: no unit
+    // the next streaming slot's ring fill: its descriptor is read (from the kernel arguments) only when a wave's own stream has
+    // left the ring -- nothing of it is live during the phase
+    auto fill = [&c, wg](const unsigned ring_lds, const int wave, const int lane) {
+        if constexpr (NEXT >= 0) {
+            if (c.ph[NEXT].kind != PK_PH_NONE) {
+                const int ngx = c.ph[NEXT].gx, nby = wg / ngx;
+                const int nbx = nby < c.ph[NEXT].ks ? wg - nby * ngx : c.ph[NEXT].a.units;
+                PkStream<WF> ns;
+                ns.init(c.ph[NEXT].a, c.ph[NEXT].kind == PK_PH_SWIGLU ? 2 : 1, nbx, nby, ngx, wave);
+                for (int k = 0; k < pk_ring_depth(0) && k < ns.T; ++k) ns.next(ring_lds, k * 1024, lane);
+            }
+        }
+    };
+    pk_phase<MT, WF, EPI, 1>(c.ph[SLOT].a, bx, by, gx, smem, prefetched, fill);
+}
+
+template <int MT, int WF>
+__global__ __launch_bounds__(512, 2) void pk_chain_kernel(const PkChainArgs c) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pk_smem_dyn[];
+    const int wg = static_cast<int>(blockIdx.x), nwg = static_cast<int>(gridDim.x);
+    volatile int *bar_ok = reinterpret_cast<volatile int *>(pk_smem_dyn + c.flag_off);
+    unsigned epoch = 0;
+    int nstamp = 0;
+    auto stamp = [&]() __attribute__((always_inline)) {
+        if (c.stamps && threadIdx.x == 0 && nstamp < 16) c.stamps[wg * 16 + nstamp] = __builtin_amdgcn_s_memrealtime();
+        ++nstamp;
+    };
+    // behind the last barrier of the launch: the last workgroup to get here puts the barrier words back to zero
+    auto leave = [&]() __attribute__((always_inline)) {
+        stamp();
+        if (epoch > 0 && threadIdx.x == 0) {
+            pk_gu32 *w = (pk_gu32 *)c.sync;
+            if (__hip_atomic_fetch_add(w + 17 * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == static_cast<unsigned>(nwg) - 1u)
+                for (int i = 0; i < 18; ++i) __hip_atomic_store(w + i * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    stamp();
+    bool pre = false;   // the running slot's first ring elements were issued by its predecessor
+    const bool u0 = c.ph[0].kind != PK_PH_NONE, u1 = c.ph[1].kind != PK_PH_NONE, u2 = c.ph[2].kind != PK_PH_NONE,
+               u3 = c.ph[3].kind != PK_PH_NONE, u4 = c.ph[4].kind != PK_PH_NONE;
+    if (u0) {
+        pk_chain_slot<MT, WF, 0, PK_EPI_PLAIN, 1>(c, pk_smem_dyn, wg, false);
+        pre = u1;
+        stamp();
+        if ((u1 || u2 || u3 || u4) && !pk_grid_barrier(c.sync, c.err, ++epoch, wg, nwg, bar_ok)) return;
+        stamp();
+    }
+    if (u1) {
+        pk_chain_slot<MT, WF, 1, PK_EPI_SWIGLU, 2>(c, pk_smem_dyn, wg, pre);
+        pre = u2;
+        stamp();
+        if ((u2 || u3 || u4) && !pk_grid_barrier(c.sync, c.err, ++epoch, wg, nwg, bar_ok)) return;
+        stamp();
+    }
+    if (u2) {
+        if (c.ph[2].kind == PK_PH_SLAB) pk_chain_slot<MT, WF, 2, PK_EPI_SLAB, 4>(c, pk_smem_dyn, wg, pre);
+        else pk_chain_slot<MT, WF, 2, PK_EPI_PLAIN, 4>(c, pk_smem_dyn, wg, pre);
+        pre = u4;
+        stamp();
+        if ((u3 || u4) && !pk_grid_barrier(c.sync, c.err, ++epoch, wg, nwg, bar_ok)) return;
+        stamp();
+    }
+    if (u3) {
+        // y = scale * sum of the K-slice slabs (+ residual): pk_slab_reduce_kernel's arithmetic, 4 columns per thread
+        const PkArgs &a = c.ph[3].a;
+        const size_t total4 = static_cast<size_t>(a.M) * a.N / 4, slab_sz = static_cast<size_t>(a.M) * a.N;
+        for (size_t i = static_cast<size_t>(wg) * 512 + threadIdx.x; i < total4; i += static_cast<size_t>(nwg) * 512) {
+            const size_t e0 = i * 4;
+            const int n = static_cast<int>(e0 % a.N), m = static_cast<int>(e0 / a.N);
+            floatx4 v = *reinterpret_cast<const floatx4 *>(a.slab + e0);
+            for (int k = 1; k < c.ph[3].ks; ++k) v += *reinterpret_cast<const floatx4 *>(a.slab + k * slab_sz + e0);
+            half4_t o, res{0, 0, 0, 0};
+            if (a.residual) res = *reinterpret_cast<const half4_t *>(a.residual + (a.res_x32 ? x32_offset(m, n) : e0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float f = v[e];
+                if (a.scale) f *= c.ph[3].scale_f32 ? reinterpret_cast<const float *>(a.scale)[n + e] : to_f32(reinterpret_cast<const half_t *>(a.scale)[n + e]);
+                if (a.residual) f += to_f32(res[e]);
+                o[e] = from_f32<half_t>(f);
+            }
+            *reinterpret_cast<half4_t *>(a.y + (a.y_x32 ? x32_offset(m, n) : e0)) = o;
+        }
+        stamp();
+        if (u4 && !pk_grid_barrier(c.sync, c.err, ++epoch, wg, nwg, bar_ok)) return;
+        stamp();
+    }
+    if (u4) pk_chain_slot<MT, WF, 4, PK_EPI_PLAIN, -1>(c, pk_smem_dyn, wg, pre);
+    leave();
 }
 
 // ---- packers: row-major weights of the reference layout -> tile-packed image ----

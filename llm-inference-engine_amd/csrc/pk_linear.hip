@@ -205,6 +205,125 @@ int pk_linear(int wf, const half_t *x, const void *Wp, const void *scale, half_t
     return launch_status("linear(packed)");
 }
 
+// ---- persistent chain launch (pk_chain_kernel): host side ----
+// The phases are planned exactly as pk_linear plans the separate launches (same units, K slices, LDS carve), so a phase computes
+// what its launch computes; the chain needs every workgroup resident (one 512-thread workgroup per CU on a 256-CU device).
+static bool pk_chain_device_ok() {
+    static const bool ok = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+        return cus >= 256;
+    }();
+    return ok;
+}
+void pk_chain_begin(PkChain *ch, int wf, int M) {
+    ch->wf = wf;
+    ch->M = M;
+    ch->nph = 0;
+    ch->lds = 0;
+    // (int4 at 17-32 rows: that instantiation's scalar spills reach scratch memory -- VMEM operations the hand-counted waits do not
+    // know about: no chain there; tests/test_abi_cpu.py holds every other instantiation to zero scratch)
+    ch->ok = pk_chain_device_ok() && M >= 1 && M <= 32 && !(wf == PK_I4 && M > 16);
+    ch->stamps = nullptr;
+    PkChainArgs &c = *reinterpret_cast<PkChainArgs *>(ch->args);
+    for (PkChainPhase &ph : c.ph) {
+        ph = PkChainPhase{};
+        ph.kind = PK_PH_NONE;
+        ph.gx = 1;
+        ph.ks = 1;
+    }
+}
+// slot: 0 = O projection (PLAIN), 1 = gate/up (SWIGLU), 2 = down (PLAIN; a K split adds the reduce slot 3), 4 = next QKV (PLAIN)
+int pk_chain_add(PkChain *ch, int slot, const half_t *x, const void *Wp, const void *scale, half_t *y, int K, int N, int epi, int x32_flags,
+                 const half_t *residual, const half_t *gamma, const half_t *pre_bias, float eps, float *slab_ws, size_t slab_ws_floats) {
+    const int wf = ch->wf, M = ch->M;
+    PkChainArgs &c = *reinterpret_cast<PkChainArgs *>(ch->args);
+    static_assert(sizeof(PkChainArgs) <= sizeof(ch->args), "PkChain::args too small");
+    auto fail = [&](const char *why) {
+        ch->ok = false;
+        set_error("linear(packed chain): %s (M=%d K=%d N=%d)", why, M, K, N);
+        return LLMIE_ERR_UNSUPPORTED;
+    };
+    if (!ch->ok) return fail("chain not available");
+    if (!(x32_flags & PK_X32_X)) return fail("every phase reads the x32 activation image");
+    if (!pk_eligible(wf, M, K, N, epi) || (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(Wp) | reinterpret_cast<uintptr_t>(gamma) |
+                                            reinterpret_cast<uintptr_t>(pre_bias)) % 16 ||
+        reinterpret_cast<uintptr_t>(y) % 8 || reinterpret_cast<uintptr_t>(residual) % 8 || (wf != PK_F16 && !scale) ||
+        (gamma && K > PK_NORM_MAX_K) || (gamma && residual))
+        return fail("unsupported shape / alignment");
+    const int units = epi == PK_EPI_SWIGLU ? pk_tiles(N, 1) / 2 : pk_tiles(N, 0);
+    PkPlan p;
+    if (!pk_plan(wf, K, units, epi != PK_EPI_SWIGLU && !gamma, &p)) return fail("K does not fit the register-resident activation slice");
+    const int y_x32 = (x32_flags & PK_X32_Y) ? 1 : 0, res_x32 = (x32_flags & PK_X32_RES) ? 1 : 0;
+    if (K % 32 || (y_x32 && (epi == PK_EPI_SWIGLU ? N / 2 : N) % 32) || (res_x32 && N % 32)) return fail("x32 layout needs multiples of 32 columns");
+    const bool slot_ok = (slot == 0 && epi == PK_EPI_PLAIN && p.KS == 1) || (slot == 1 && epi == PK_EPI_SWIGLU) || (slot == 2 && epi == PK_EPI_PLAIN) ||
+                         (slot == 4 && epi == PK_EPI_PLAIN && p.KS == 1);
+    if (!slot_ok || c.ph[slot].kind != PK_PH_NONE) return fail("projection does not fit its chain slot");
+    const int mt = (M + 15) / 16;
+    ++ch->nph;
+    PkChainPhase &ph = c.ph[slot];
+    ph.a = PkArgs{x, static_cast<const unsigned char *>(Wp), M, K, N, units, K / pk_kb(wf), p.bps, y, nullptr, scale, residual, 1, y_x32, res_x32,
+                  gamma, pre_bias, eps};
+    ph.kind = epi == PK_EPI_SWIGLU ? PK_PH_SWIGLU : PK_PH_PLAIN;
+    ph.gx = p.gx;
+    ph.ks = p.KS;
+    ph.scale_f32 = 0;
+    int kepi = epi;
+    if (p.KS > 1) {
+        if (!slab_ws || slab_ws_floats < static_cast<size_t>(p.KS) * M * N || reinterpret_cast<uintptr_t>(slab_ws) % 16) return fail("split-K workspace too small");
+        ph.a.slab = slab_ws;
+        ph.a.residual = nullptr;
+        ph.kind = PK_PH_SLAB;
+        kepi = PK_EPI_SLAB;
+        ++ch->nph;
+        PkChainPhase &rd = c.ph[3];
+        rd.a = ph.a;
+        rd.a.scale = wf == PK_I8 || wf == PK_FP8 ? scale : nullptr;
+        rd.a.residual = residual;
+        rd.kind = PK_PH_REDUCE;
+        rd.gx = 1;
+        rd.ks = p.KS;
+        rd.scale_f32 = wf == PK_FP8 ? 1 : 0;
+    }
+    const int lds = pk_lds(mt, kepi, gamma ? (pre_bias ? 2 * K : K) : 0, kepi == PK_EPI_PLAIN && residual).total;
+    if (lds > 160 * 1024 - 16) return fail("LDS carve too large");
+    ch->lds = lds > ch->lds ? lds : ch->lds;
+    return LLMIE_OK;
+}
+template <int MT, int WF> static void pk_chain_launch_t(const PkChainArgs &c, int lds, hipStream_t st) {
+    static const bool attr_set = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pk_chain_kernel<MT, WF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return true;
+    }();
+    (void)attr_set;
+    pk_chain_kernel<MT, WF><<<256, 512, lds, st>>>(c);
+}
+int pk_chain_launch(PkChain *ch, unsigned *sync, unsigned *err, hipStream_t st) {
+    PkChainArgs &c = *reinterpret_cast<PkChainArgs *>(ch->args);
+    if (!ch->ok || ch->nph < 1 || !sync || !err) {
+        set_error("linear(packed chain): nothing to launch");
+        return LLMIE_ERR_UNSUPPORTED;
+    }
+    c.nph = ch->nph;
+    c.sync = sync;
+    c.err = err;
+    c.stamps = ch->stamps;
+    c.flag_off = (ch->lds + 15) & ~15;
+    const int lds = c.flag_off + 16;
+    const int mt = (ch->M + 15) / 16;
+#define LLMIE_CHAIN(WF_) (mt == 1 ? pk_chain_launch_t<1, WF_>(c, lds, st) : pk_chain_launch_t<2, WF_>(c, lds, st))
+    switch (ch->wf) {
+        case PK_F16: LLMIE_CHAIN(PK_F16); break;
+        case PK_I8: LLMIE_CHAIN(PK_I8); break;
+        case PK_FP8: LLMIE_CHAIN(PK_FP8); break;
+        case PK_I4: LLMIE_CHAIN(PK_I4); break;
+        default: set_error("linear(packed chain): unknown format"); return LLMIE_ERR_UNSUPPORTED;
+    }
+#undef LLMIE_CHAIN
+    return launch_status("linear(packed chain)");
+}
+size_t pk_chain_sync_bytes() { return PK_SYNC_WORDS * sizeof(unsigned); }
+
 }  // namespace llmie
 
 using namespace llmie;

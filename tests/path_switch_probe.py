@@ -46,7 +46,8 @@ for bs in (2, 20):
     vc = (torch.randn((L, bs, nh, max_seq, hs), generator=g) * 0.5).to(DEV).to(F16)
     x = torch.randn((bs, H), generator=g).to(DEV).to(F16)
     res["decode_b%d" % bs] = dec.forward(x, torch.empty_like(x), kc, vc, 300).float().cpu().numpy()
-    if bs == 2 and wfmt != "int8":
+    dec.status()   # (a grid barrier of the persistent chain launch that timed out raises here)
+    if bs == 2:
         lens = torch.tensor([70, 40], dtype=torch.int32, device=DEV)
         xs = torch.randn((110, H), generator=g).to(DEV).to(F16)
         kz, vz = torch.zeros_like(kc), torch.zeros_like(vc)

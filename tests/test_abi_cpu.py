@@ -86,6 +86,22 @@ def test_packed_kernels_do_not_spill():
     assert all(k["vgpr"] <= 256 for k in ks)
 
 
+def test_chain_kernels_use_no_scratch():
+    """pk_chain_kernel runs pk_phase's hand-counted DMA waits: no instantiation the host will launch may touch scratch memory (the
+    32-row int4 one does and is excluded by pk_chain_begin)"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("ckr", os.path.join(root, "tools", "check_kernel_resources.py"))
+    ckr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ckr)
+    obj = os.path.join(root, "llm-inference-engine_amd", "csrc", "_obj", "pk_linear.hip.o")
+    ks = [k for k in ckr.kernel_metadata(obj) if "pk_chain_kernel" in k["name"]]
+    assert len(ks) == 8
+    bad = [k for k in ks if (k["vgpr_spill"] or k["scratch"]) and "ILi2ELi4E" not in k["name"]]
+    assert not bad, bad
+
+
 def test_eight_phase_gemm_kernels_do_not_spill():
     """gemm8p.cuh counts its LDS-DMA by hand (inline asm) and runs one 512-thread workgroup per CU, 2 waves per
     SIMD: every instantiation (fp16 / e4m3, with and without epilogue, SwiGLU, both tile widths) must fit 256 VGPRs without

@@ -17,6 +17,7 @@ SWITCHES = [
     ("LLMIE_NO_PACKED_BATCH", "int8"),        # 4 < batch <= 32: split-K batch path instead of the packed-weight path
     ("LLMIE_NO_FUSED_SHORT_PREFILL", "f16"),  # <= 128 tokens: prefill-sized launch sequence instead of the slab-fused one
     ("LLMIE_NO_NORM_QUANT", "fp8"),           # fp8 prefill: RMSNorm + quantise as two launches
+    ("LLMIE_CHAIN", "int8"),                  # opt-in: 4 < batch <= 32 as attention + ONE persistent chain launch per layer instead of six launches
 ]
 
 
@@ -39,6 +40,8 @@ def test_switched_path_matches_the_default_path(tmp_path, switch, wfmt):
         assert np.isfinite(a).all() and np.isfinite(b).all()
         tol = 6e-2 if wfmt == "fp8" else 3e-2
         assert (np.abs(a - b) <= tol + tol * np.abs(a)).all(), "%s / %s: max diff %g" % (switch, k, np.abs(a - b).max())
+        if switch == "LLMIE_CHAIN":   # the chain's phases ARE the launches' code (pk_phase): same arithmetic, same order
+            assert np.array_equal(a, b), "%s / %s: the chain launch is not bit-identical to the launch sequence" % (switch, k)
 
 
 def test_no_other_switches_are_read():
