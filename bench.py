@@ -356,13 +356,17 @@ def main():
         start_step = max(1, S - (K + W) + 1)
         step_dev = torch.tensor([start_step], dtype=torch.int32, device=dev)
 
+        # One token step = 32 layers on the hidden state of the current token -> final norm + LM head -> top-k round 1 -> ONE tail
+        # launch (top-k round 2, sampling, the NEXT token's input embedding into `hidden`, step counter += 1; round 3:
+        # llmie_lm_head_sample_next, four launches less per step) -> token to pinned host memory.  The first token's embedding is
+        # gathered once in front of the loop (it is the tail of the prompt's last step in a real run).
+        llmie.input_embedding(ids, weights["embed"], hidden)
+
         def one_step():
-            llmie.input_embedding(ids, weights["embed"], hidden)
             dec.forward(hidden, hidden, kc, vc, -1, step_dev=step_dev)
             dec.lm_head_sample(hidden, weights["final_norm"], weights["lm_head"], llmie.W_F16, logits, tmp_ids, tmp_vals,
                                top_ids, top_vals, seq_len, finished, ids, step=-1, end_id=-1, blocks_per_row=BPR,
-                               step_dev=step_dev)
-            llmie.advance_step(step_dev)
+                               step_dev=step_dev, embed=weights["embed"], next_hidden=hidden, advance=True)
             host_tok.copy_(ids, non_blocking=True)
 
         stream = torch.cuda.Stream()

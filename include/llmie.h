@@ -331,7 +331,26 @@ typedef struct {
      * head_size 64/128 decode, 128 prefill, head_num/kv_head_num in {1,2,4}); a scale <= 0 means 1. */
     llmie_kv_format kv_fmt;
     float k_scale, v_scale;
+    /* ABI 3: LLMIE_DEC_* bits (0 = the round-2 behaviour) */
+    int flags;
 } llmie_decoder_config;
+
+/* Weight residency (ABI 3).  An engine whose max_batch lies above the GEMV range (fp16 3, int8 / fp8 2, int4 1 rows) builds
+ * tile-packed images of its four matrices per layer inside its workspace at create time -- a SNAPSHOT: weights updated in place
+ * afterwards are seen by the batch <= GEMV-range and prefill paths, not by the packed one; create synchronises the device before
+ * it packs, so uploads on any stream have landed.  By default that image is a second copy next to the caller's row-major matrices.
+ *   LLMIE_DEC_NO_PACKED_COPY  no image is built: batches 4..32 take the split-K batch path on the row-major weights (slower there,
+ *                             nothing doubled).
+ *   LLMIE_DEC_PACKED_ONLY     the images are the ONLY weights the engine reads after create: the `data` arrays of the four
+ *                             matrices of every layer may be freed or reused once llmie_decoder_create has returned (scales,
+ *                             biases and norm gammas stay referenced).  Needs max_batch <= 32 (fp8: 16) and shapes the packed
+ *                             kernels take; every decode batch runs on the packed kernels, prefill (fp16 / int8 / int4) unpacks
+ *                             one matrix at a time into its workspace.  An int8 Llama-2-7B decoder is then resident at ~6.5 GB
+ *                             instead of ~13 GB.
+ * llmie_decoder_resident_weight_bytes: bytes of layer-matrix storage (row-major matrices that must stay + images) of a config. */
+#define LLMIE_DEC_NO_PACKED_COPY 1
+#define LLMIE_DEC_PACKED_ONLY 2
+size_t llmie_decoder_resident_weight_bytes(const llmie_decoder_config *cfg);
 
 typedef struct llmie_decoder llmie_decoder; /* opaque */
 
@@ -405,6 +424,17 @@ int llmie_lm_head_sample(llmie_decoder *dec, void *hidden /* [bs,H]; clobbered (
                          int K, int blocks_per_row, int32_t *seq_len, uint8_t *finished,
                          int32_t *out_ids, int batch, int step, const int32_t *step_dev,
                          int end_id, llmie_stream stream);
+
+/* ABI 3.  llmie_lm_head_sample with the tail of the step fused into ONE launch behind round 1 of the top-k: round 2 + sampling
+ * (bit-identical ids / values / picks / seq_len / finished) + -- if next_hidden != NULL -- the next step's input embedding
+ * (next_hidden[b, :] = embed_table[out_ids[b], :], llmie_input_embedding's rule for ids outside the table; llama.cpp:219 of the
+ * next token) + -- if advance_step != 0 -- *step_dev += 1 once every row has read it (llmie_advance_step).  Replaces four
+ * launches of the batch-1 step (top-k round 2, sampling, advance_step, input_embedding). */
+int llmie_lm_head_sample_next(llmie_decoder *dec, void *hidden, const void *final_norm_gamma, const llmie_matrix *lm_head,
+                              llmie_weight_format lm_fmt, void *logits, int32_t *tmp_ids, void *tmp_vals, int32_t *topk_ids,
+                              void *topk_vals, int K, int blocks_per_row, int32_t *seq_len, uint8_t *finished, int32_t *out_ids,
+                              int batch, int step, int32_t *step_dev, int end_id, const void *embed_table, void *next_hidden,
+                              int advance_step, llmie_stream stream);
 
 /* Per-kernel timing of the engine (eager launches only, never inside graph capture): between
  * profile_begin and profile_end every kernel the engine launches is bracketed by hipEvents

@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libllmie.so")
 F32, F16 = 0, 1
 W_F16, W_INT8, W_INT4, W_FP8, W_F32 = 0, 1, 2, 3, 4
 KV_NATIVE, KV_FP8 = 0, 1
+DEC_NO_PACKED_COPY, DEC_PACKED_ONLY = 1, 2
 ABI_VERSION = 3  # LLMIE_ABI_VERSION of include/llmie.h this binding mirrors
 
 _lib = None
@@ -89,6 +90,8 @@ _SIGS = {
     "llmie_decoder_prefill": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp],
     "llmie_lm_head_sample": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp,
                              _i, _vp],
+    "llmie_lm_head_sample_next": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp,
+                                  _i, _vp],
     "llmie_advance_step": [_vp, _vp],
     "llmie_decoder_forward_paged": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "llmie_decoder_prefill_paged": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _sz, _vp],
@@ -96,6 +99,7 @@ _SIGS = {
     "llmie_decoder_profile_begin": [_vp, _i],
     "llmie_decoder_profile_end": [_vp, _vp, _vp, _vp],
     "llmie_decoder_status": [_vp, _vp],
+    "llmie_decoder_resident_weight_bytes": [_vp],
     "llmie_decoder_debug_stamps": [_vp, _vp],
     "llmie_abi_version": [],
     "llmie_last_error": [],
@@ -103,6 +107,7 @@ _SIGS = {
 }
 _RESTYPES = {
     "llmie_decoder_mha_workspace_bytes": _sz,
+    "llmie_decoder_resident_weight_bytes": _sz,
     "llmie_linear_fp8_workspace_bytes": _sz,
     "llmie_linear_workspace_bytes": _sz,
     "llmie_packed_weight_bytes": _sz,
@@ -366,7 +371,7 @@ class DecoderConfig(C.Structure):
     _fields_ = [("head_num", _i), ("kv_head_num", _i), ("head_size", _i), ("inter_size", _i), ("num_layers", _i),
                 ("vocab_size", _i), ("max_seq_len", _i), ("max_batch", _i), ("rotary_dim", _i),
                 ("rotary_base", _f), ("rms_eps", _f), ("dtype", _i), ("wfmt", _i), ("int4_group", _i),
-                ("kv_fmt", _i), ("k_scale", _f), ("v_scale", _f)]
+                ("kv_fmt", _i), ("k_scale", _f), ("v_scale", _f), ("flags", _i)]
 
 
 def _mat(m):
@@ -451,8 +456,18 @@ class Decoder:
         return hidden_out
 
     def lm_head_sample(self, hidden, final_gamma, lm_head, lm_fmt, logits, tmp_ids, tmp_vals, topk_ids, topk_vals,
-                       seq_len, finished, out_ids, step, end_id, blocks_per_row=8, step_dev=None):
+                       seq_len, finished, out_ids, step, end_id, blocks_per_row=8, step_dev=None, embed=None, next_hidden=None,
+                       advance=False, fused_tail=False):
+        """fused_tail (or embed / advance): llmie_lm_head_sample_next -- top-k round 2 + sampling (+ next_hidden[b] = embed[out_ids[b]])
+        (+ step_dev += 1) in one launch"""
         m = _mat(lm_head)
+        if fused_tail or embed is not None or advance:
+            _check(lib().llmie_lm_head_sample_next(self.handle, _p(hidden), _p(final_gamma), C.byref(m), lm_fmt, _p(logits),
+                                                   _p(tmp_ids), _p(tmp_vals), _p(topk_ids), _p(topk_vals), topk_ids.shape[-1],
+                                                   blocks_per_row, _p(seq_len), _p(finished), _p(out_ids), hidden.shape[0], step,
+                                                   _p(step_dev), end_id, _p(embed), _p(next_hidden), 1 if advance else 0, _st()),
+                   "lm_head_sample_next")
+            return
         _check(lib().llmie_lm_head_sample(self.handle, _p(hidden), _p(final_gamma), C.byref(m), lm_fmt, _p(logits),
                                           _p(tmp_ids), _p(tmp_vals), _p(topk_ids), _p(topk_vals),
                                           topk_ids.shape[-1], blocks_per_row, _p(seq_len), _p(finished), _p(out_ids),

@@ -32,6 +32,7 @@ struct llmie_decoder {
     void *fp8_ws;        // LLMIE_W_FP8 engines: activation quantisation + split-K scratch of llmie_linear_fp8
     size_t fp8_ws_bytes;
     SlabWs slab_ws;      // fp32 slabs of the split-K projections (batch path, row-major engines)
+    unsigned *tail_ticket = nullptr;   // one zeroed word: arrival ticket of the fused decode tail (llmie_lm_head_sample_next)
     int ragged = 0;      // set for the duration of a *_ragged forward: step_dev is the per-sequence context-length array
     // packed-weight batch path (gemv_max < batch <= 32): tile-packed images of the four matrices of every layer (built once at
     // create time into the caller's workspace: the MI355X's 288 GB buy a second, stream-friendly copy of the weights), the
@@ -42,6 +43,7 @@ struct llmie_decoder {
     };
     std::vector<PackedLayer> packed;
     int pk_wf = 0;                    // PKF_* of the engine's weight format, 0 = no packed path
+    bool packed_only = false;         // LLMIE_DEC_PACKED_ONLY: the row-major matrices are gone, every path reads the images
     half_t *hx = nullptr, *actx = nullptr;   // x32 images: residual stream [32, H], SwiGLU output [32, I]
     half_t *mhax = nullptr;                  // x32 image of the attention output [32, H]
     float *pk_slab = nullptr;
@@ -96,6 +98,8 @@ static bool config_ok(const llmie_decoder_config *c) {
     if (c->dtype == LLMIE_F32 && c->wfmt != LLMIE_W_F32) return false;
     if (c->dtype == LLMIE_F16 && c->wfmt == LLMIE_W_F32) return false;
     if (c->kv_fmt != LLMIE_KV_NATIVE && c->kv_fmt != LLMIE_KV_FP8) return false;
+    if (c->flags & ~(LLMIE_DEC_NO_PACKED_COPY | LLMIE_DEC_PACKED_ONLY)) return false;
+    if ((c->flags & LLMIE_DEC_NO_PACKED_COPY) && (c->flags & LLMIE_DEC_PACKED_ONLY)) return false;
     if (c->kv_fmt == LLMIE_KV_FP8) {  // e4m3 cache: fp16 engines on the fused attention kernels only
         const int rep = c->head_num / c->kv_head_num;
         if (c->dtype != LLMIE_F16 || (c->head_size != 128 && c->head_size != 64) || (rep != 1 && rep != 2 && rep != 4)) return false;
@@ -133,7 +137,9 @@ static int packed_wf(const llmie_decoder_config *c) {
                    : (c->wfmt == LLMIE_W_INT8 ? PKF_I8 : (c->wfmt == LLMIE_W_FP8 ? PKF_FP8 : (c->wfmt == LLMIE_W_INT4 && c->int4_group == 128 ? PKF_I4 : 0)));
     // batches up to the GEMV crossover never take the packed path: no second copy of the weights for such engines
     const int gemv_max = gemv_max_batch(c->wfmt);
-    if (!wf || c->max_batch <= gemv_max) return 0;
+    const bool only = (c->flags & LLMIE_DEC_PACKED_ONLY) != 0;   // the images are all there is: built whatever the batch
+    if (!wf || (c->flags & LLMIE_DEC_NO_PACKED_COPY) || (!only && c->max_batch <= gemv_max)) return 0;
+    if (only && c->max_batch > (wf == PKF_FP8 ? 16 : 32)) return 0;
     const int H = c->head_num * c->head_size, QKV = (c->head_num + 2 * c->kv_head_num) * c->head_size, I = c->inter_size;
     const int m = c->max_batch < 32 ? c->max_batch : 32;
     const int mm = m;
@@ -230,6 +236,25 @@ extern "C" size_t llmie_decoder_workspace_bytes(const llmie_decoder_config *cfg)
     return carve(cfg, offs);
 }
 
+extern "C" size_t llmie_decoder_resident_weight_bytes(const llmie_decoder_config *cfg) {
+    if (!config_ok(cfg)) return 0;
+    const size_t H = static_cast<size_t>(cfg->head_num) * cfg->head_size, QKV = static_cast<size_t>(cfg->head_num + 2 * cfg->kv_head_num) * cfg->head_size;
+    const size_t I = cfg->inter_size, elems = QKV * H + H * H + 3 * H * I, rows = QKV + H + 2 * I + H;
+    size_t row_major = 0, scales = 0;
+    switch (cfg->wfmt) {
+        case LLMIE_W_F16: row_major = elems * 2; break;
+        case LLMIE_W_F32: row_major = elems * 4; break;
+        case LLMIE_W_INT8: row_major = elems; scales = rows * 2; break;
+        case LLMIE_W_FP8: row_major = elems; scales = rows * 4; break;
+        case LLMIE_W_INT4: row_major = elems / 2; scales = (elems / (cfg->int4_group > 0 ? cfg->int4_group : 128)) * 2; break;
+        default: return 0;
+    }
+    const int wf = packed_wf(cfg);
+    const size_t images = wf ? packed_carve(cfg, wf).layer_bytes : 0;
+    const size_t per_layer = ((cfg->flags & LLMIE_DEC_PACKED_ONLY) && wf ? 0 : row_major) + scales + images;
+    return per_layer * cfg->num_layers;
+}
+
 extern "C" llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg, const llmie_layer_weights *layers,
                                                void *workspace, size_t workspace_bytes) {
     if (!config_ok(cfg)) {
@@ -280,6 +305,12 @@ extern "C" llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg, 
     d->attn_ws = base + offs[6];
     d->attn_ws_bytes = llmie_decoder_mha_workspace_bytes(cfg->max_batch, cfg->head_num, cfg->head_size, cfg->max_seq_len);
     d->rope_table = reinterpret_cast<float2 *>(base + offs[7]);
+    d->tail_ticket = reinterpret_cast<unsigned *>(base + offs[8]);
+    if (hipMemset(d->tail_ticket, 0, 256) != hipSuccess) {
+        set_error("decoder_create: clearing the workspace words failed");
+        delete d;
+        return nullptr;
+    }
     d->fp8_ws = base + offs[9];
     {
         const int kmax = cfg->inter_size > d->H ? cfg->inter_size : d->H;
@@ -288,7 +319,18 @@ extern "C" llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg, 
     d->slab_ws = SlabWs{reinterpret_cast<float *>(base + offs[11]), engine_slab_floats(cfg, cfg->max_batch)};
     if (!d->slab_ws.floats) d->slab_ws.p = nullptr;
     d->pk_wf = packed_wf(cfg);
+    if ((cfg->flags & LLMIE_DEC_PACKED_ONLY) && !d->pk_wf) {
+        set_error("decoder_create: LLMIE_DEC_PACKED_ONLY needs max_batch <= 32 (fp8: 16) and shapes / a format the packed kernels take");
+        delete d;
+        return nullptr;
+    }
     if (d->pk_wf) {
+        // (uploads of the weights on other streams -- torch side streams are non-blocking -- must have landed before they are packed)
+        if (hipDeviceSynchronize() != hipSuccess) {
+            set_error("decoder_create: device synchronise failed");
+            delete d;
+            return nullptr;
+        }
         // one-time re-tiling of every matrix into the stream-friendly image (null stream, synchronous: create is not on the
         // compute path); the row-major originals stay in use for batch <= gemv_max (GEMV) and for prefill
         const PackedCarve pc = packed_carve(cfg, d->pk_wf);
@@ -322,6 +364,10 @@ extern "C" llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg, 
             set_error("decoder_create: packing the weights for the batch path failed");
             delete d;
             return nullptr;
+        }
+        if (cfg->flags & LLMIE_DEC_PACKED_ONLY) {   // the caller may free the row-major matrices now: forget them
+            d->packed_only = true;
+            for (llmie_layer_weights &w : d->layers) w.qkv.data = w.o.data = w.gate_up.data = w.down.data = nullptr;
         }
     }
     {
@@ -507,7 +553,7 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
     const bool int4_ok = wbits == 4 && c.int4_group == 128 && batch <= 64;  // int4 MFMA form: group-128 scales, 64 rows per pass
     const bool batch_path_ok = !batch_fused_off && c.dtype == LLMIE_F16 && (wbits == 16 || wbits == 8 || int4_ok || fp8) && hs_ok &&
                                rep_ok && batch <= 128 && H % 256 == 0 && I % 256 == 0 && H >= 512 && I >= 512 && splitk_rownorm_eligible(H);
-    const bool gemv_ok = (batch <= gemv_max || !batch_path_ok) &&
+    const bool gemv_ok = !dec->packed_only && (batch <= gemv_max || !batch_path_ok) &&
                          (wbits == 16 ? gemv_f16_eligible(batch, H, h, dec->layers[0].qkv.data)
                                       : ((wbits != 0 || fp8) && ksplit_eligible(batch, H, fp8 ? 8 : wbits)));
     if (!fused_off && c.dtype == LLMIE_F16 && (wbits != 0 || fp8) && hs_ok && rep_ok && H % 8 == 0 && gemv_ok) {
@@ -572,7 +618,11 @@ extern "C" int llmie_decoder_forward(llmie_decoder *dec, const void *hidden_in, 
     // fp8: the per-launch activation quantisation (amax + conversions of the whole register slice) costs ~5 us at 32 rows;
     // measured (7B, ctx 512, tokens/s packed vs split-K batch path): b8 2705 / 2506, b16 5011 / 4450, b24 5656 / 5833, b32 7103 / 7120
     const int pk_rows_max = fp8 ? 16 : 32;
-    if (!packed_off && !fused_off && dec->pk_wf && batch > gemv_max && batch <= pk_rows_max && hs_ok && rep_ok) {
+    if (dec->packed_only && (packed_off || fused_off || batch > pk_rows_max || !hs_ok || !rep_ok)) {
+        set_error("decoder_forward: a LLMIE_DEC_PACKED_ONLY engine decodes on the packed kernels only (batch <= %d, no path switch)", pk_rows_max);
+        return LLMIE_ERR_UNSUPPORTED;
+    }
+    if (!packed_off && !fused_off && dec->pk_wf && (batch > gemv_max || dec->packed_only) && batch <= pk_rows_max && hs_ok && rep_ok) {
         hipStream_t st = as_stream(stream);
         const int wf = dec->pk_wf;
         half_t *hh = static_cast<half_t *>(h);
@@ -819,7 +869,7 @@ static size_t prefill_carve(const llmie_decoder_config *c, int T, int B, size_t 
     // int8 / int4 engines at prefill-sized T: room for the fp16 image of the largest matrix (projections without an in-kernel
     // de-quantising form: int4, and int8 shapes whose 256-row grid does not fill the chip)
     size_t dq = 0;
-    if (c->wfmt == LLMIE_W_INT8 || c->wfmt == LLMIE_W_INT4) {
+    if (c->wfmt == LLMIE_W_INT8 || c->wfmt == LLMIE_W_INT4 || (c->flags & LLMIE_DEC_PACKED_ONLY)) {
         const int bits = c->wfmt == LLMIE_W_INT8 ? 8 : 4;
         const size_t shapes[4][2] = {{H, QKV}, {H, H}, {H, 2 * I}, {I, H}};
         (void)bits;
@@ -895,6 +945,43 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
     // Short prefills (<= 128 tokens, fp16 weights) are weight-stream bound like a decode batch: same launch fusion as the batch
     // decode path -- every projection leaves split-K slabs, the O and down slabs are consumed by the row kernel (reduction +
     // residual stream + the next RMSNorm), the gate/up slabs by the SwiGLU finalize: 9 launches per layer instead of 13.
+    if (dec->packed_only) {
+        // LLMIE_DEC_PACKED_ONLY: the row-major matrices are gone -- every projection unpacks its tile-packed image (scales applied,
+        // one fp16 rounding per weight: the numerics of the int4 prefill) into the workspace and runs the fp16 GEMM on it
+        if (fp8) LLMIE_UNSUPPORTED("decoder_prefill: LLMIE_DEC_PACKED_ONLY engines prefill fp16 / int8 / int4 weights only");
+        const size_t img_need = static_cast<size_t>(H > QKV ? H : QKV) * (I > H ? I : H);   // (an upper bound is carved: 2 I x H)
+        (void)img_need;
+        auto pproj = [&](const void *img, const void *scale, int swiglu_img, const half_t *x, half_t *y, int K, int N, int epi,
+                         const half_t *residual) -> int {
+            if (deq_bytes < static_cast<size_t>(N) * K * sizeof(half_t)) {
+                set_error("decoder_prefill: workspace holds no room for the fp16 image of a %d x %d matrix", N, K);
+                return LLMIE_ERR_WORKSPACE;
+            }
+            int rc2 = pk_unpack_f16(dec->pk_wf, img, static_cast<const half_t *>(scale), static_cast<half_t *>(deq), N, K, swiglu_img, st);
+            if (rc2) return rc2;
+            return linear_f16_nk(x, static_cast<const half_t *>(deq), y, T, K, N, epi, nullptr, residual, slabs, st);
+        };
+        for (int l = 0; l < c.num_layers; ++l) {
+            const llmie_layer_weights &w = dec->layers[l];
+            const llmie_decoder::PackedLayer &pw = dec->packed[l];
+            TIMED(LLMIE_OP_ATTN_NORM, llmie_rmsnorm(h, resid, w.attn_norm_gamma, c.rms_eps, T, H, LLMIE_F16, stream));
+            TIMED(LLMIE_OP_QKV_GEMM, pproj(pw.qkv, w.qkv.scale, 0, h, qkv, H, QKV, EPI_NONE_, nullptr));
+            TIMED(LLMIE_OP_MHA, prefill_attention_f16(qkv, (const half_t *)w.qkv.bias, k_cache, v_cache, attn, cum, history_lengths,
+                                                      dec->rope_table, l, batch, T, max_q_len, c.head_num, c.kv_head_num, c.head_size,
+                                                      c.max_seq_len, c.rotary_dim, st, c.kv_fmt == LLMIE_KV_FP8, c.k_scale > 0.f ? c.k_scale : 1.f,
+                                                      c.v_scale > 0.f ? c.v_scale : 1.f, dec->page_table, dec->max_pages, dec->num_pages));
+            TIMED(LLMIE_OP_O_GEMM, pproj(pw.o, w.o.scale, 0, attn, h, H, H, EPI_NONE_, nullptr));
+            TIMED(LLMIE_OP_FFN_NORM, llmie_fused_add_bias_residual_rmsnorm(resid, h, w.o.bias, w.ffn_norm_gamma, c.rms_eps, T, H, LLMIE_F16, stream));
+            if (T <= 192 || gemm256_swiglu_fills(T, 2 * I)) {
+                TIMED(LLMIE_OP_GATE_UP_SWIGLU, pproj(pw.gate_up, w.gate_up.scale, 1, h, act, H, 2 * I, EPI_SWIGLU_, nullptr));
+            } else {
+                TIMED(LLMIE_OP_GATE_UP_SWIGLU, pproj(pw.gate_up, w.gate_up.scale, 1, h, gu, H, 2 * I, EPI_NONE_, nullptr));
+                TIMED(LLMIE_OP_GATE_UP_SWIGLU, llmie_silu_and_mul(gu, act, T, I, LLMIE_F16, stream));
+            }
+            TIMED(LLMIE_OP_DOWN_GEMM, pproj(pw.down, w.down.scale, 0, act, h, I, H, EPI_NONE_, resid));
+        }
+        return LLMIE_OK;
+    }
     static const bool short_off = getenv("LLMIE_NO_FUSED_SHORT_PREFILL") != nullptr;
     const int sbits = wqbits ? wqbits : 16;   // split-K kernels' weight-format code
     const bool short_fmt_ok = !fp8 && (wqbits != 4 || (c.int4_group == 128 && T <= 64));   // int4 split-K form: 64 rows, group 128
@@ -999,11 +1086,11 @@ extern "C" int llmie_decoder_prefill_paged(llmie_decoder *dec, const void *hidde
     return rc;
 }
 
-extern "C" int llmie_lm_head_sample(llmie_decoder *dec, void *hidden, const void *final_norm_gamma,
-                                    const llmie_matrix *lm_head, llmie_weight_format lm_fmt, void *logits,
-                                    int32_t *tmp_ids, void *tmp_vals, int32_t *topk_ids, void *topk_vals, int K,
-                                    int blocks_per_row, int32_t *seq_len, uint8_t *finished, int32_t *out_ids,
-                                    int batch, int step, const int32_t *step_dev, int end_id, llmie_stream stream) {
+static int lm_head_sample_impl(llmie_decoder *dec, void *hidden, const void *final_norm_gamma, const llmie_matrix *lm_head,
+                               llmie_weight_format lm_fmt, void *logits, int32_t *tmp_ids, void *tmp_vals, int32_t *topk_ids,
+                               void *topk_vals, int K, int blocks_per_row, int32_t *seq_len, uint8_t *finished, int32_t *out_ids,
+                               int batch, int step, int32_t *step_dev, int end_id, const void *embed_table, void *next_hidden,
+                               int advance_step, bool fused_tail, llmie_stream stream) {
     LLMIE_REQUIRE(dec && hidden && final_norm_gamma && lm_head && lm_head->data && logits && topk_ids && topk_vals &&
                       seq_len && finished && out_ids, "lm_head_sample: NULL pointer");
     const llmie_decoder_config &c = dec->cfg;
@@ -1023,10 +1110,42 @@ extern "C" int llmie_lm_head_sample(llmie_decoder *dec, void *hidden, const void
     TIMED(LLMIE_OP_LM_HEAD, engine_linear(dec, lm_fmt, hidden, *lm_head, logits, batch, dec->H, c.vocab_size, false, nullptr,
                                           false, stream));
     }
+    if (fused_tail) {
+        // llama.cpp:293-318 (+ :219 of the next token): round 1 of the top-k, then ONE launch for round 2, the sampling, the next
+        // step's input embedding and the step counter
+        LLMIE_REQUIRE(K >= 1 && K <= 32 && K <= c.vocab_size && blocks_per_row >= 1 && blocks_per_row <= 64 && tmp_ids && tmp_vals,
+                      "lm_head_sample_next: K=%d / blocks_per_row=%d outside [1, 32] / [1, 64], or tmp buffers missing", K, blocks_per_row);
+        TIMED(LLMIE_OP_TOPK, topk_round1_only(logits, tmp_ids, tmp_vals, batch, c.vocab_size, K, blocks_per_row, c.dtype, as_stream(stream)));
+        TIMED(LLMIE_OP_SAMPLING, decode_tail(tmp_ids, tmp_vals, topk_ids, topk_vals, K, blocks_per_row, seq_len, finished, out_ids, batch, step,
+                                             step_dev, end_id, c.vocab_size, embed_table, next_hidden, dec->H, advance_step, dec->tail_ticket,
+                                             c.dtype, as_stream(stream)));
+        return LLMIE_OK;
+    }
     // llama.cpp:293,304
     TIMED(LLMIE_OP_TOPK, llmie_topk(logits, tmp_ids, tmp_vals, topk_ids, topk_vals, batch, c.vocab_size, K, blocks_per_row,
                                     c.dtype, stream));
     TIMED(LLMIE_OP_SAMPLING, llmie_sampling(topk_ids, topk_vals, seq_len, finished, out_ids, batch, K, step, step_dev, end_id,
                                             c.vocab_size, c.dtype, stream));
     return LLMIE_OK;
+}
+
+extern "C" int llmie_lm_head_sample(llmie_decoder *dec, void *hidden, const void *final_norm_gamma,
+                                    const llmie_matrix *lm_head, llmie_weight_format lm_fmt, void *logits,
+                                    int32_t *tmp_ids, void *tmp_vals, int32_t *topk_ids, void *topk_vals, int K,
+                                    int blocks_per_row, int32_t *seq_len, uint8_t *finished, int32_t *out_ids,
+                                    int batch, int step, const int32_t *step_dev, int end_id, llmie_stream stream) {
+    return lm_head_sample_impl(dec, hidden, final_norm_gamma, lm_head, lm_fmt, logits, tmp_ids, tmp_vals, topk_ids, topk_vals, K, blocks_per_row,
+                               seq_len, finished, out_ids, batch, step, const_cast<int32_t *>(step_dev), end_id, nullptr, nullptr, 0, false, stream);
+}
+
+extern "C" int llmie_lm_head_sample_next(llmie_decoder *dec, void *hidden, const void *final_norm_gamma, const llmie_matrix *lm_head,
+                                         llmie_weight_format lm_fmt, void *logits, int32_t *tmp_ids, void *tmp_vals, int32_t *topk_ids,
+                                         void *topk_vals, int K, int blocks_per_row, int32_t *seq_len, uint8_t *finished, int32_t *out_ids,
+                                         int batch, int step, int32_t *step_dev, int end_id, const void *embed_table, void *next_hidden,
+                                         int advance_step, llmie_stream stream) {
+    LLMIE_REQUIRE(!next_hidden || embed_table, "lm_head_sample_next: next_hidden without an embedding table");
+    LLMIE_REQUIRE(!advance_step || step_dev, "lm_head_sample_next: advance_step needs the device-resident step");
+    LLMIE_REQUIRE(tmp_ids && tmp_vals, "lm_head_sample_next: tmp buffers required");
+    return lm_head_sample_impl(dec, hidden, final_norm_gamma, lm_head, lm_fmt, logits, tmp_ids, tmp_vals, topk_ids, topk_vals, K, blocks_per_row,
+                               seq_len, finished, out_ids, batch, step, step_dev, end_id, embed_table, next_hidden, advance_step, true, stream);
 }

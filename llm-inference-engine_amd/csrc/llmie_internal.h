@@ -90,6 +90,8 @@ enum : int { PKX_X = 1, PKX_Y = 2, PKX_RES = 4 };                               
 size_t pk_packed_bytes(int wf, int N, int K, int swiglu);
 size_t pk_packed_scale_bytes(int wf, int N, int K, int swiglu);   // int4: the group-scale image beside the weight image (else 0)
 int pk_pack(int wf, const void *src, const void *src_scale, void *dst, void *dst_scale, int N, int K, int swiglu, hipStream_t st);
+// image -> fp16 row-major [N, K] with the scales applied (fp16 / int8 / int4 images; scale = the caller's row / group-128 scales)
+int pk_unpack_f16(int wf, const void *packed, const half_t *scale, half_t *w16, int N, int K, int swiglu, hipStream_t st);
 bool pk_eligible(int wf, int M, int K, int N, int epi);
 size_t pk_slab_floats(int wf, int M, int K, int N);
 int pk_linear(int wf, const half_t *x, const void *Wp, const void *scale, half_t *y, int M, int K, int N, int epi, int x32_flags,
@@ -126,6 +128,13 @@ int decoder_mha_rope(const void *qkv, const void *qkv_bias, void *k_cache, void 
                      int max_pages = 0, int num_pages = 0,
                      int ragged = 0 /* step_dev is an array: step_dev[b] = context length of sequence b incl. this token */,
                      int out_x32 = 0 /* out is the x32 activation image (batch <= 32) instead of row-major [batch, H] */);
+
+// fused tail of a decode step (topk_sampling.hip): round 1 of the top-k alone, and round 2 + sampling (+ the next step's input
+// embedding into next_hidden, + *step_dev += 1 by the last row to finish; `ticket` = one zeroed word) in one launch
+int topk_round1_only(const void *probs, int32_t *tmp_ids, void *tmp_vals, int rows, int vocab, int K, int bpr, llmie_dtype dtype, hipStream_t st);
+int decode_tail(const int32_t *tmp_ids, const void *tmp_vals, int32_t *ids, void *vals, int K, int bpr, int32_t *seq_len, uint8_t *finished,
+                int32_t *out_id, int rows, int step, int32_t *step_dev, int end_id, int vocab, const void *embed, void *next_hidden, int hidden,
+                int advance, unsigned *ticket, llmie_dtype dtype, hipStream_t st);
 
 // prefill attention (RoPE + KV append + flash attention) on the packed QKV buffer; prefill.hip
 int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, void *k_cache, void *v_cache, half_t *out,

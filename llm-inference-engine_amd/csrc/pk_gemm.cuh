@@ -1078,6 +1078,53 @@ __global__ __launch_bounds__(256) void pk_pack_kernel(const unsigned char *__res
     }
 }
 
+// tile-packed image -> fp16 row-major [N, K] with the format's scales applied (the inverse of pk_pack_kernel followed by the
+// de-quantisation of quant_linear.hip's dequant_f16_kernel: fp16(code * scale), one rounding).  One thread per 16-byte image chunk.
+// Used by the prefill of LLMIE_DEC_PACKED_ONLY engines (the row-major matrices are gone): one matrix at a time into the prefill
+// workspace, then the fp16 GEMM.  scale: int8 fp16 [N]; int4 fp16 [N, K / 128] (the caller's arrays, which stay referenced).
+template <int WF>
+__global__ __launch_bounds__(256) void pk_unpack_f16_kernel(const uint4_t *__restrict__ src, const half_t *__restrict__ scale,
+                                                            half_t *__restrict__ w16, int N, int K, int tiles, int swiglu) {
+    using F = PkFmt<WF>;
+    const int nblk = K / F::KB;
+    const size_t total = static_cast<size_t>(tiles) * nblk * 64;
+    for (size_t c = blockIdx.x * 256ull + threadIdx.x; c < total; c += static_cast<size_t>(gridDim.x) * 256) {
+        const int l = static_cast<int>(c & 63), r = l & 15, q = l >> 4;
+        const size_t tb = c >> 6;
+        const int j = static_cast<int>(tb % nblk), tile = static_cast<int>(tb / nblk);
+        const int row = pk_src_row(tile, r, N, swiglu);
+        if (row >= N) continue;
+        const uint4_t v = src[c];
+        half_t *dst = w16 + static_cast<size_t>(row) * K;
+        if constexpr (WF == PK_F16) {
+            *reinterpret_cast<uint4_t *>(dst + 32 * j + 8 * q) = v;
+        } else if constexpr (WF == PK_I8) {
+            const float sc = to_f32(scale[row]);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                half8_t o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned w = v[2 * s2 + (e >> 2)];
+                    o[e] = from_f32<half_t>(static_cast<float>(static_cast<int8_t>((w >> (8 * (e & 3))) & 0xffu)) * sc);
+                }
+                *reinterpret_cast<half8_t *>(dst + 64 * j + 32 * s2 + 8 * q) = o;
+            }
+        } else {
+            static_assert(WF == PK_I4, "unpack: fp16 / int8 / int4 images");
+            const float sc = to_f32(scale[static_cast<size_t>(row) * (K / 128) + j]);
+            constexpr int pos[8] = {0, 4, 1, 5, 2, 6, 3, 7};   // image nibble pos[i] holds k = i (pk_pack_kernel)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                half8_t o;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = from_f32<half_t>(static_cast<float>(static_cast<int>((v[s2] >> (4 * pos[i])) & 0xfu) - 8) * sc);
+                *reinterpret_cast<half8_t *>(dst + 128 * j + 32 * s2 + 8 * q) = o;
+            }
+        }
+    }
+}
+
 // int4 group-128 scales [N, K/128] fp16 -> [tiles][nblk][16 rows] (one 32-byte record per block; lane group q reads 8 bytes)
 static __global__ __launch_bounds__(256) void pk_pack_scale4_kernel(const half_t *__restrict__ src, half_t *__restrict__ dst, int N,
                                                                   int K, int tiles, int swiglu) {

@@ -88,6 +88,22 @@ static bool pk_plan(int wf, int K, int units, bool may_split, PkPlan *p) {
     return best_cost != (1 << 30);
 }
 
+int pk_unpack_f16(int wf, const void *packed, const half_t *scale, half_t *w16, int N, int K, int swiglu, hipStream_t st) {
+    if (!pk_packed_bytes(wf, N, K, swiglu) || wf == PK_FP8 || (wf != PK_F16 && !scale) || (wf == PK_I4 && K % 128) ||
+        (reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(w16)) % 16) {
+        set_error("unpack_weight: fp16 / int8 / int4 images with their scales, 16-byte aligned buffers (N=%d K=%d)", N, K);
+        return LLMIE_ERR_UNSUPPORTED;
+    }
+    const int tiles = pk_tiles(N, swiglu);
+    const size_t chunks = static_cast<size_t>(tiles) * (K / pk_kb(wf)) * 64;
+    const int grid = static_cast<int>(chunks / 256 > 8192 ? 8192 : (chunks + 255) / 256);
+    const uint4_t *s = static_cast<const uint4_t *>(packed);
+    if (wf == PK_F16) pk_unpack_f16_kernel<PK_F16><<<grid, 256, 0, st>>>(s, scale, w16, N, K, tiles, swiglu);
+    else if (wf == PK_I8) pk_unpack_f16_kernel<PK_I8><<<grid, 256, 0, st>>>(s, scale, w16, N, K, tiles, swiglu);
+    else pk_unpack_f16_kernel<PK_I4><<<grid, 256, 0, st>>>(s, scale, w16, N, K, tiles, swiglu);
+    return launch_status("unpack_weight");
+}
+
 int x32_convert(const half_t *src, half_t *dst, int M, int K, int to_x32, hipStream_t st) {
     if (M < 1 || M > 32 || K <= 0 || K % 32 || (reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) % 16) {
         set_error("x32_convert: needs 1 <= M <= 32, K %% 32 == 0, 16-byte aligned buffers");

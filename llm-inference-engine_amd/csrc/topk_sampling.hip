@@ -212,6 +212,147 @@ __global__ __launch_bounds__(64) void sampling_kernel(const int32_t *__restrict_
 
 __global__ void advance_step_kernel(int32_t *step) { *step += 1; }
 
+// ---------------- fused tail of a decode step (round 3) ----------------
+// top-k round 2 + sampling + the next step's input embedding + the step counter in ONE launch (llama.cpp:293-318 then :219 of the
+// next token: four launches of ~4.5 us each in the batch-1 step).  One wave per sequence: the round-2 merge of the row's
+// blocks_per_row * K candidates exactly as topk_round2_kernel does it (the butterfly leaves the winner of every round in all lanes,
+// so the K results stay in registers, rounded to T as the unfused kernel stores them), then lane 0 samples with sampling_kernel's
+// arithmetic, the wave copies the chosen token's embedding row into next_hidden[row] (input_embedding's rule: ids outside the table
+// are skipped), and the LAST wave to finish (a ticket every row takes after it has read the step) advances *step_dev.
+template <typename T, int KMAX>
+__global__ __launch_bounds__(64) void decode_tail_kernel(const int32_t *__restrict__ tmp_ids, const T *__restrict__ tmp_vals,
+                                                         int32_t *__restrict__ ids, T *__restrict__ vals, int K, int bpr,
+                                                         int32_t *__restrict__ seq_len, uint8_t *__restrict__ finished,
+                                                         int32_t *__restrict__ out_id, int rows, int step_arg, int32_t *step_dev,
+                                                         int end_id, int vocab, const T *__restrict__ embed, T *__restrict__ next_hidden,
+                                                         int hidden, int advance, unsigned *ticket) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const int step = step_dev ? *step_dev : step_arg;
+    const int n = bpr * K;
+    TopList<KMAX> tl;
+    tl.init();
+    for (int i = lane; i < n; i += 64) {
+        const int id = tmp_ids[static_cast<size_t>(row) * n + i];
+        if (id >= 0) tl.insert(to_f32(tmp_vals[static_cast<size_t>(row) * n + i]), id, K);
+    }
+    int sid[KMAX];
+    float sval[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        sid[k] = -1;
+        sval[k] = 0.f;
+        if (k < K) {
+            float bv = tl.v[0];
+            int bi = tl.id[0];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (better(ov, oi, bv, bi)) {
+                    bv = ov;
+                    bi = oi;
+                }
+            }
+            if (bi != INT_MAX && tl.id[0] == bi) tl.pop();
+            const T stored = from_f32<T>(bv);
+            sid[k] = (bi == INT_MAX) ? -1 : bi;
+            sval[k] = to_f32(stored);
+            if (lane == 0) {
+                ids[static_cast<size_t>(row) * K + k] = sid[k];
+                vals[static_cast<size_t>(row) * K + k] = stored;
+            }
+        }
+    }
+    // sampling_kernel's arithmetic on the K candidates (identical in every lane; lane 0 stores)
+    int first = -1;
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i)
+        if (i < K && first < 0 && sid[i] >= 0) first = i;
+    int chosen = end_id;
+    if (first >= 0) {
+        float v0 = 0.f;
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i)
+            if (i == first) v0 = sval[i];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i)
+            if (i < K && i >= first && sid[i] >= 0) sum += expf(sval[i] - v0);
+        float thr = uniform_philox(static_cast<uint32_t>(step), static_cast<uint32_t>(row)) * sum;
+        bool done = false;
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) {
+            if (i == first) chosen = sid[i] % vocab;
+        }
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) {
+            if (i < K && i >= first && sid[i] >= 0 && !done) {
+                thr -= expf(sval[i] - v0);
+                if (thr < 0.f) {
+                    chosen = sid[i] % vocab;
+                    done = true;
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        out_id[row] = chosen;
+        if (!finished[row]) ++seq_len[row];
+        finished[row] = static_cast<uint8_t>(chosen == end_id);
+    }
+    if (next_hidden && chosen >= 0 && chosen < vocab) {
+        constexpr int N = 16 / sizeof(T);
+        const T *src = embed + static_cast<size_t>(chosen) * hidden;
+        T *dst = next_hidden + static_cast<size_t>(row) * hidden;
+        if (hidden % N == 0 && (reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) % 16 == 0) {
+            for (int i = lane; i < hidden / N; i += 64) reinterpret_cast<uint4_t *>(dst)[i] = reinterpret_cast<const uint4_t *>(src)[i];
+        } else {
+            for (int i = lane; i < hidden; i += 64) dst[i] = src[i];
+        }
+    }
+    if (advance && step_dev && lane == 0) {
+        // every row has read the step before it takes its ticket: the last one moves the counter and re-zeroes the ticket word
+        if (atomicAdd(ticket, 1u) == static_cast<unsigned>(rows) - 1u) {
+            *step_dev = step + 1;
+            atomicExch(ticket, 0u);
+        }
+    }
+}
+
+int topk_round1_only(const void *probs, int32_t *tmp_ids, void *tmp_vals, int rows, int vocab, int K, int bpr, llmie_dtype dtype, hipStream_t st) {
+    if (dtype == LLMIE_F16) {
+        const half_t *p = static_cast<const half_t *>(probs);
+        const bool vec_ok = vocab % Vec16<half_t>::n == 0 && reinterpret_cast<uintptr_t>(p) % 16 == 0;
+        if (K <= 8) topk_round1_kernel<half_t, 8><<<rows * bpr, 256, 0, st>>>(p, tmp_ids, static_cast<half_t *>(tmp_vals), vocab, K, bpr, vec_ok);
+        else topk_round1_kernel<half_t, 32><<<rows * bpr, 256, 0, st>>>(p, tmp_ids, static_cast<half_t *>(tmp_vals), vocab, K, bpr, vec_ok);
+    } else {
+        const float *p = static_cast<const float *>(probs);
+        const bool vec_ok = vocab % Vec16<float>::n == 0 && reinterpret_cast<uintptr_t>(p) % 16 == 0;
+        if (K <= 8) topk_round1_kernel<float, 8><<<rows * bpr, 256, 0, st>>>(p, tmp_ids, static_cast<float *>(tmp_vals), vocab, K, bpr, vec_ok);
+        else topk_round1_kernel<float, 32><<<rows * bpr, 256, 0, st>>>(p, tmp_ids, static_cast<float *>(tmp_vals), vocab, K, bpr, vec_ok);
+    }
+    return launch_status("topk(round 1)");
+}
+
+int decode_tail(const int32_t *tmp_ids, const void *tmp_vals, int32_t *ids, void *vals, int K, int bpr, int32_t *seq_len, uint8_t *finished,
+                int32_t *out_id, int rows, int step, int32_t *step_dev, int end_id, int vocab, const void *embed, void *next_hidden, int hidden,
+                int advance, unsigned *ticket, llmie_dtype dtype, hipStream_t st) {
+#define LLMIE_TAIL(T_, KM_)                                                                                                         \
+    decode_tail_kernel<T_, KM_><<<rows, 64, 0, st>>>(tmp_ids, static_cast<const T_ *>(tmp_vals), ids, static_cast<T_ *>(vals), K, bpr, seq_len, \
+                                                     finished, out_id, rows, step, step_dev, end_id, vocab, static_cast<const T_ *>(embed),   \
+                                                     static_cast<T_ *>(next_hidden), hidden, advance, ticket)
+    if (dtype == LLMIE_F16) {
+        if (K <= 8) LLMIE_TAIL(half_t, 8);
+        else LLMIE_TAIL(half_t, 32);
+    } else {
+        if (K <= 8) LLMIE_TAIL(float, 8);
+        else LLMIE_TAIL(float, 32);
+    }
+#undef LLMIE_TAIL
+    return launch_status("decode_tail");
+}
+
+
 }  // namespace llmie
 
 using namespace llmie;

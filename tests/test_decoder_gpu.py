@@ -159,3 +159,52 @@ def test_decoder_rejects_bad_arguments(llmie):
         llmie.Decoder(dict(head_num=3, kv_head_num=2, head_size=32, inter_size=64, num_layers=1, vocab_size=10,
                            max_seq_len=8, max_batch=1, rotary_dim=32, rotary_base=1e4, rms_eps=1e-5,
                            dtype=llmie.F16, wfmt=llmie.W_F16, int4_group=128), [])
+
+
+def test_fused_decode_tail_matches_the_launch_sequence(llmie):
+    """llmie_lm_head_sample_next (round 3): top-k round 2 + sampling + next-token embedding + step advance in one launch gives,
+    bit for bit, what llmie_lm_head_sample + llmie_advance_step + llmie_input_embedding give (ids, values, picks, seq_len,
+    finished, next hidden, step), for K = 4 / 5 / 20, several rows, ties and an end_id hit"""
+    F16 = torch.float16
+    rng = np.random.default_rng(91)
+    nh, hs, I, L, V, max_seq = 8, 128, 1024, 1, 3000, 64
+    H = nh * hs
+    u = lambda shape, s: torch.from_numpy((rng.uniform(-1, 1, shape) * s).astype(np.float32)).to(DEV).to(F16)
+    layer = dict(attn_norm=u((H,), 0.2) + 1, ffn_norm=u((H,), 0.2) + 1, qkv=dict(data=u((3 * H, H), 0.06)), o=dict(data=u((H, H), 0.06)),
+                 gate_up=dict(data=u((2 * I, H), 0.06)), down=dict(data=u((H, I), 0.06)))
+    for bs, K, bpr in ((1, 4, 8), (5, 5, 8), (32, 20, 3), (3, 4, 1)):
+        cfg = dict(head_num=nh, kv_head_num=nh, head_size=hs, inter_size=I, num_layers=L, vocab_size=V, max_seq_len=max_seq, max_batch=bs,
+                   rotary_dim=hs, rotary_base=10000.0, rms_eps=1e-5, dtype=llmie.F16, wfmt=llmie.W_F16, int4_group=128)
+        dec = llmie.Decoder(cfg, [layer])
+        hidden = u((bs, H), 1.0)
+        gam, lm, embed = u((H,), 0.2) + 1, u((V, H), 0.3), u((V, H), 1.0)
+        lm[7] = lm[11]   # an exact tie among the logits
+        outs = []
+        for fused in (False, True):
+            h = hidden.clone()
+            logits = torch.empty((bs, V), dtype=F16, device=DEV)
+            t_ids = torch.empty((bs, bpr, K), dtype=torch.int32, device=DEV)
+            t_vals = torch.empty((bs, bpr, K), dtype=F16, device=DEV)
+            f_ids = torch.empty((bs, K), dtype=torch.int32, device=DEV)
+            f_vals = torch.empty((bs, K), dtype=F16, device=DEV)
+            seq = torch.arange(bs, dtype=torch.int32, device=DEV)
+            fin = torch.zeros(bs, dtype=torch.uint8, device=DEV)
+            fin[bs // 2] = 1
+            out_ids = torch.empty(bs, dtype=torch.int32, device=DEV)
+            step_dev = torch.tensor([17], dtype=torch.int32, device=DEV)
+            nxt = torch.full((bs, H), -9.0, dtype=F16, device=DEV)
+            end_id = 0
+            if fused:
+                dec.lm_head_sample(h, gam, lm, llmie.W_F16, logits, t_ids, t_vals, f_ids, f_vals, seq, fin, out_ids, step=-1, end_id=end_id,
+                                   blocks_per_row=bpr, step_dev=step_dev, embed=embed, next_hidden=nxt, advance=True)
+            else:
+                dec.lm_head_sample(h, gam, lm, llmie.W_F16, logits, t_ids, t_vals, f_ids, f_vals, seq, fin, out_ids, step=-1, end_id=end_id,
+                                   blocks_per_row=bpr, step_dev=step_dev)
+                llmie.advance_step(step_dev)
+                llmie.input_embedding(out_ids, embed, nxt)
+            torch.cuda.synchronize()
+            outs.append([t.clone() for t in (f_ids, f_vals, out_ids, seq, fin, step_dev, nxt)])
+        for a, b, name in zip(outs[0], outs[1], ("topk ids", "topk vals", "picks", "seq_len", "finished", "step", "next hidden")):
+            assert torch.equal(a, b), "bs %d K %d: %s differ" % (bs, K, name)
+        assert int(outs[1][5].item()) == 18
+        dec.close()
