@@ -487,11 +487,11 @@ def main():
         return el, pprof, flops
 
     def rocprof_ref(key):
-        """kernel averages of the committed rocprofv3 runs of these same configurations (profiles/r02_rocprof_roofline.json,
+        """kernel averages of the committed rocprofv3 runs of these same configurations (profiles/r03_rocprof_roofline.json,
         written by tools/summarize_prof.py from the kernel traces / PMC passes): the trace-side counterpart of the live
         hipEvent numbers"""
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_rocprof_roofline.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r03_rocprof_roofline.json")) as f:
                 return json.load(f).get(key)
         except (OSError, ValueError):
             return None
@@ -511,7 +511,9 @@ def main():
             blk["rocprof_avg_us"] = ref.get("avg_us")
             if ref.get("avg_us"):
                 blk["frac_rocprof_trace"] = round(work_per_launch / (ref["avg_us"] * 1e-6) / scale / peak, 4)
-            blk["traffic"] = ref.get("hbm_bytes_per_launch")
+            blk["traffic"] = ref.get("hbm_bytes_per_launch")   # PMC passes of exactly this kernel name and grid, or None
+            blk["traffic_source"] = ref.get("traffic_source")
+            blk["rocprof_kernel"], blk["rocprof_grid"] = ref.get("kernel"), ref.get("grid")
             blk["rocprof_source"] = ref.get("source")
         return blk
 
@@ -585,6 +587,14 @@ def main():
             extra[name] = dict(tokens_per_s=round(b * s / el, 1), ms=round(el * 1e3, 3), batch=b, seq=s,
                                TFLOP_per_s=round(flops / el / 1e12, 1),
                                frac_of_mfma_peak=round(flops / el / (5.0e15 if wfmt == "fp8" else 2.5e15), 4))
+            # the HBM side of the same pass: layer weights once + K / V rows written (short prefills are weight-stream bound:
+            # at 128 tokens the pass is ~128 FLOP/B, below the ridge)
+            wb_ = {"f16": 2.0, "int8": 1.0, "fp8": 1.0, "int4": 0.5 + 2.0 / 128}[wfmt]
+            Hh, KVH, I_, L_ = H, cfg["kv_head_num"] * cfg["head_size"], cfg["inter_size"], cfg["num_layers"]
+            hb = L_ * ((Hh + 2 * KVH) * Hh + Hh * Hh + 3 * Hh * I_) * wb_ + b * s * L_ * 2 * KVH * 2
+            extra[name]["algorithmic_GB_hbm"] = round(hb / 1e9, 3)
+            extra[name]["frac_of_hbm_peak"] = round(hb / el / 1e9 / HBM_PEAK_GBS, 4)
+            extra[name]["bound"] = "hbm" if flops / hb < 2.5e15 / (HBM_PEAK_GBS * 1e9) else "mfma"
             return pr
 
         if os.environ.get("LLMIE_BENCH_SMALL_BATCH_SWEEP"):  # development: small-batch decode over the weight formats
@@ -654,6 +664,20 @@ def main():
         for b in (32, 128):
             record("decode_f16_b%d_ctx512" % b, "f16", weights["layers"], b, 512, 2.0)
         out["extra"] = extra
+        try:   # bytes of layer-matrix storage an engine keeps resident, per format and residency flag (llmie_decoder_resident_weight_bytes)
+            import ctypes as C_
+            lib_ = llmie.lib()
+            res = {}
+            for nm, wf_ in (("f16", llmie.W_F16), ("int8", llmie.W_INT8), ("int4", llmie.W_INT4), ("fp8", llmie.W_FP8)):
+                for tag, mb, fl in (("b1", 1, 0), ("b32", 32, 0), ("b32_packed_only", 32, llmie.DEC_PACKED_ONLY), ("b32_no_packed_copy", 32, llmie.DEC_NO_PACKED_COPY)):
+                    if nm == "fp8" and mb == 32 and fl == llmie.DEC_PACKED_ONLY:
+                        mb = 16
+                    c_ = llmie.DecoderConfig(**dict(cfg, max_seq_len=2048, max_batch=mb, rotary_dim=cfg["head_size"], rotary_base=10000.0, rms_eps=1e-5,
+                                                    dtype=llmie.F16, wfmt=wf_, int4_group=128, kv_fmt=0, k_scale=1.0, v_scale=1.0, flags=fl))
+                    res["%s_%s" % (nm, tag)] = round(lib_.llmie_decoder_resident_weight_bytes(C_.byref(c_)) / 1e9, 3)
+            out["resident_layer_weight_GB"] = res
+        except Exception as e:   # a side report must never take the bench line down
+            out["resident_layer_weight_GB"] = {"error": str(e)[:200]}
 
         # ---- the peak constants used above, with on-box measurements beside them: a device copy, and the
         #      vendor library GEMM (torch.matmul = hipBLASLt/rocBLAS) next to this library's GEMM at the same prefill shape

@@ -225,11 +225,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const void *__restrict__ X
         if (kt + 1 < KT) dma_tile(kt + 1, stage ^ 1);  // lands while this k-tile is multiplied
         const unsigned char *ab = a_base + stage * STAGE_BYTES, *bb = b_base + stage * STAGE_BYTES;
         if constexpr (FP8) {
-            // lane (r, q) supplies k bytes [32q, 32q + 32) of its row: slots 2q and 2q + 1 (any lane -> k assignment is
-            // fine as long as both operands use the same one)
+            // lane (r, q) supplies k bytes [16q, +16) and [64 + 16q, +16) of its row: chunks q and 4 + q (any lane -> k assignment is
+            // fine as long as both operands use the same one; this one is conflict-free under the row & 7 swizzle)
             auto frag8 = [&](const unsigned char *base, int row) {
-                const uint4_t lo = *reinterpret_cast<const uint4_t *>(base + row * 128 + (((2 * q) ^ (row & 7)) << 4));
-                const uint4_t hi = *reinterpret_cast<const uint4_t *>(base + row * 128 + (((2 * q + 1) ^ (row & 7)) << 4));
+                const uint4_t lo = *reinterpret_cast<const uint4_t *>(base + row * 128 + ((q ^ (row & 7)) << 4));
+                const uint4_t hi = *reinterpret_cast<const uint4_t *>(base + row * 128 + (((4 + q) ^ (row & 7)) << 4));
                 return intx8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
             };
             intx8 bf[WN];

@@ -55,27 +55,34 @@ template <bool FP8> __device__ __forceinline__ void g8_mma(floatx4 &acc, const G
 }
 // ---- weight-only int8 B operand (WQ = 8; round 3: prefill of int8 engines, context_decoder.cpp:58-199 on int8 [N, K] weights) ----
 // The weight tile travels HBM/L2 -> LDS as RAW int8 (64 bytes per row and 64-deep k-tile: half the DMA and LDS-fill bytes of the
-// fp16 form) and is de-quantised when a wave reads its fragment: one ds_read_b128 = the lane's 16 weights of one row, k = 16 q ..
-// 16 q + 15 of the k-tile; bytes 0-7 feed k-step 0 and bytes 8-15 k-step 1, and the activation fragments are read with the SAME k
-// assignment (16-byte chunks 2q and 2q + 1 of the row, the mapping the e4m3 form already uses) -- any k order is a valid
-// contraction as long as both operands agree.  De-quantisation is exact: byte ^ 0x80 under the fp16 exponent 0x64 is 1152 + w, and
-// a packed fp16 subtract of 1152 leaves w (integers below 2048 are exact in fp16); the per-row scale meets the fp32 accumulator in
-// the epilogue, so the numerics are "fp16 activations x integer weights, fp32 accumulate, one scale, one rounding" -- what the
-// int8 decode kernels compute.  LDS image of a B half: 128 rows x 64 B; slot c of row r holds source chunk c ^ ((-(r >> 2)) & 3)
-// (applied on the DMA source address): the 16 lanes of every ds_read_b128 service group then hit 16 different 16-byte bank groups.
-__device__ __forceinline__ unsigned g8_q8_slot(int row, int chunk) { return static_cast<unsigned>((chunk ^ (-(row >> 2))) & 3); }
-__device__ __forceinline__ void g8_read_q8(G8Frag<false> &f, const unsigned char *p) {
-    const uint4_t w = *reinterpret_cast<const uint4_t *>(p);
+// fp16 form) and is de-quantised when a wave reads its fragment.  Lane (r, q) multiplies, in k-step s, the k = 32 s + 8 q .. + 7 of
+// the k-tile -- the assignment of the fp16 form, so the activation fragments are read exactly as there (16-byte chunks q and 4 + q
+// of the row under the row & 7 swizzle: conflict-free; the "k = 16 q .. 16 q + 15 per lane" assignment that a single 16-byte weight
+// read per lane would want costs every ACTIVATION read a 2-way bank conflict under the same swizzle: profiles/r03, 0.44 conflict
+// cycles per LDS cycle, MFMA busy 52 % against 67 %) -- and fetches its 8 weights of a k-step with one ds_read_b64: bytes
+// [32 s + 8 q, + 8) of the row.  De-quantisation is exact: byte ^ 0x80 under the fp16 exponent 0x64 is 1152 + w, and a packed fp16
+// subtract of 1152 leaves w (integers below 2048 are exact in fp16); the per-row scale meets the fp32 accumulator in the epilogue,
+// so the numerics are "fp16 activations x integer weights, fp32 accumulate, one scale, one rounding" -- what the int8 decode
+// kernels compute.  LDS image of a B half: 128 rows x 64 B; the 16-byte slot c of row r holds source chunk c ^ ((r >> 2) & 3)
+// (applied on the DMA source address): the 32 lanes of a ds_read_b64 half-wave (16 rows x 2 values of q) then hit 32 different
+// 8-byte bank pairs.
+__device__ __forceinline__ unsigned g8_q8_slot(int row, int chunk) { return static_cast<unsigned>((chunk ^ (row >> 2)) & 3); }
+// byte offset, inside its 64-byte row, of the 8 weights lane (r, q) multiplies in k-step s
+__device__ __forceinline__ unsigned g8_q8_piece(int r, int q, int s) { return (g8_q8_slot(r, 2 * s + (q >> 1)) << 4) + 8u * (q & 1); }
+__device__ __forceinline__ half8_t g8_dequant8(const uint2 w) {
     const half2_t off = {static_cast<half_t>(1152.f), static_cast<half_t>(1152.f)};
-    half2_t h[8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const unsigned v = w[i] ^ 0x80808080u;
-        h[2 * i] = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(0x64646464u, v, 0x04010400u)) - off;       // {0x64, b1, 0x64, b0}
-        h[2 * i + 1] = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(0x64646464u, v, 0x04030402u)) - off;   // {0x64, b3, 0x64, b2}
-    }
-    f.k[0] = half8_t{h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]};
-    f.k[1] = half8_t{h[4][0], h[4][1], h[5][0], h[5][1], h[6][0], h[6][1], h[7][0], h[7][1]};
+    const unsigned v0 = w.x ^ 0x80808080u, v1 = w.y ^ 0x80808080u;
+    const half2_t h0 = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(0x64646464u, v0, 0x04010400u)) - off;   // {0x64, b1, 0x64, b0}
+    const half2_t h1 = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(0x64646464u, v0, 0x04030402u)) - off;   // {0x64, b3, 0x64, b2}
+    const half2_t h2 = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(0x64646464u, v1, 0x04010400u)) - off;
+    const half2_t h3 = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(0x64646464u, v1, 0x04030402u)) - off;
+    return half8_t{h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
+}
+// p = the lane's row in the LDS image; off0 / off1 = g8_q8_piece of the two k-steps
+__device__ __forceinline__ void g8_read_q8(G8Frag<false> &f, const unsigned char *p, unsigned off0, unsigned off1) {
+    const uint2 w0 = *reinterpret_cast<const uint2 *>(p + off0), w1 = *reinterpret_cast<const uint2 *>(p + off1);
+    f.k[0] = g8_dequant8(w0);
+    f.k[1] = g8_dequant8(w1);
 }
 // s_waitcnt vmcnt(n) for a run-time n (tails and prologues only; the steady state uses immediates)
 __device__ __forceinline__ void g8_wait_vm(int n) {
@@ -232,15 +239,18 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void *__restrict__ Xv
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- fragment reads: 16-byte piece k (0, 1) of row `row`: fp16 -> chunk k*4 + q (k-step k), e4m3 -> chunk 2q + k (one 128-deep step)
+    // ---- fragment reads: 16-byte piece k (0, 1) of row `row` = chunk k*4 + q (fp16: k-step k; e4m3: half of the one 128-deep step)
     const int wcol = SWIGLU ? wc * 32 : wc * 64;
-    constexpr bool K16 = FP8 || WQ != 0;   // lane q owns k = 16 q .. 16 q + 15 of the k-tile (chunks 2q, 2q + 1) instead of 8 q .. and 32 + 8 q ..
-    const unsigned sw0 = static_cast<unsigned>(((K16 ? 2 * q : q) ^ (r & 7)) << 4), sw1 = static_cast<unsigned>(((K16 ? 2 * q + 1 : 4 + q) ^ (r & 7)) << 4);
+    // every format reads its two 16-byte pieces of a row from chunks q and 4 + q: fp16 = the two 32-deep k-steps; e4m3 = 32 of the
+    // 128 k of the one MFMA step (k = 16 q .. + 15 and 64 + 16 q ..: any k assignment is a valid contraction when both operands use
+    // it, and this one is conflict-free under the row & 7 swizzle where chunks 2q, 2q + 1 -- the round-2 e4m3 assignment -- cost
+    // every ds_read_b128 a 2-way bank conflict)
+    const unsigned sw0 = static_cast<unsigned>((q ^ (r & 7)) << 4), sw1 = static_cast<unsigned>(((4 + q) ^ (r & 7)) << 4);
     const unsigned a_lane = wr * HALF_BYTES + r * 128;   // + stage, + (ih*64 + i*16) * 128, + sw
     // B piece jh, fragment jj: plain -> half 2 + (wc >> 1), row (wc & 1)*64 + jh*32 + jj*16 + r;  SwiGLU -> half 2 + jh, row wc*32 + jj*16 + r
     constexpr unsigned BROW = WQ ? 64 : 128;   // bytes of a weight row in the LDS image
-    const unsigned b_lane = (SWIGLU ? 2 * HALF_BYTES + (wc * 32 + r) * BROW : (2 + (wc >> 1)) * HALF_BYTES + ((wc & 1) * 64 + r) * BROW) +
-                            (WQ ? (g8_q8_slot(r, q) << 4) : 0u);
+    const unsigned b_lane = SWIGLU ? 2 * HALF_BYTES + (wc * 32 + r) * BROW : (2 + (wc >> 1)) * HALF_BYTES + ((wc & 1) * 64 + r) * BROW;
+    const unsigned q8o0 = g8_q8_piece(r, q, 0), q8o1 = g8_q8_piece(r, q, 1);   // (WQ) this lane's two 8-byte weight pieces of a row
     constexpr unsigned B_PIECE = SWIGLU ? HALF_BYTES : 32 * BROW;
     G8Frag<FP8> fa[4], fb0[2][2], fb1[2];   // A piece (4 row tiles), B first piece of even / odd k-tiles, B second piece
     auto read_a = [&](unsigned stage, int ih) {
@@ -252,7 +262,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void *__restrict__ Xv
         const unsigned char *p = lds + stage * STAGE_BYTES + b_lane + jh * B_PIECE;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-            if constexpr (WQ != 0) g8_read_q8(f[jj], p + jj * 16 * BROW);
+            if constexpr (WQ != 0) g8_read_q8(f[jj], p + jj * 16 * BROW, q8o0, q8o1);
             else g8_read<FP8>(f[jj], p + jj * 2048, sw0, sw1);
         }
     };
@@ -466,11 +476,11 @@ __global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict
         for (int j = 0; j < 2; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     const int wcol = SWIGLU ? wc * 16 : wc * 32;
-    constexpr bool K16 = FP8 || WQ != 0;   // lane q owns k = 16 q .. 16 q + 15 of the k-tile (as in gemm8p_kernel)
-    const unsigned sw0 = static_cast<unsigned>(((K16 ? 2 * q : q) ^ (r & 7)) << 4), sw1 = static_cast<unsigned>(((K16 ? 2 * q + 1 : 4 + q) ^ (r & 7)) << 4);
+    const unsigned sw0 = static_cast<unsigned>((q ^ (r & 7)) << 4), sw1 = static_cast<unsigned>(((4 + q) ^ (r & 7)) << 4);   // (as in gemm8p_kernel)
     // B fragment jj: plain -> slot row wc*32 + jj*16 + r; SwiGLU -> jj = 0 the gate row wc*16 + r, jj = 1 the up row 64 + wc*16 + r
     constexpr unsigned BROW = WQ ? 64 : 128;
-    const unsigned a_lane = (wr * 64 + r) * 128, b_lane = ((SWIGLU ? wc * 16 : wc * 32) + r) * BROW + (WQ ? (g8_q8_slot(r, q) << 4) : 0u);
+    const unsigned a_lane = (wr * 64 + r) * 128, b_lane = ((SWIGLU ? wc * 16 : wc * 32) + r) * BROW;
+    const unsigned q8o0 = g8_q8_piece(r, q, 0), q8o1 = g8_q8_piece(r, q, 1);
     constexpr unsigned B_STEP = SWIGLU ? 64 * BROW : 16 * BROW;
     G8Frag<FP8> fa[4], fb[3][2];   // A piece; B fragments of k-tiles u % 3 = 0, 1, 2
     auto read_a = [&](unsigned slot) {
@@ -482,7 +492,7 @@ __global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict
         const unsigned char *p = lds + slot * SLOT_BYTES + b_lane;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-            if constexpr (WQ != 0) g8_read_q8(f[jj], p + jj * B_STEP);
+            if constexpr (WQ != 0) g8_read_q8(f[jj], p + jj * B_STEP, q8o0, q8o1);
             else g8_read<FP8>(f[jj], p + jj * B_STEP, sw0, sw1);
         }
     };

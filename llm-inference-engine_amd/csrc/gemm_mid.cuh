@@ -84,9 +84,9 @@ __global__ __launch_bounds__(512) void mid_splitk_kernel(const void *__restrict_
     auto frag = [&](const unsigned char *base, int row, int c) {
         return *reinterpret_cast<const half8_t *>(base + row * 128 + ((c ^ (row & 7)) << 4));
     };
-    auto frag8 = [&](const unsigned char *base, int row) {  // fp8: lane (r, q) supplies k bytes [32q, 32q + 32) of its row
-        const uint4_t lo = *reinterpret_cast<const uint4_t *>(base + row * 128 + (((2 * q) ^ (row & 7)) << 4));
-        const uint4_t hi = *reinterpret_cast<const uint4_t *>(base + row * 128 + (((2 * q + 1) ^ (row & 7)) << 4));
+    auto frag8 = [&](const unsigned char *base, int row) {  // fp8: lane (r, q) supplies k bytes [16q, +16) and [64 + 16q, +16) of its row (chunks q, 4 + q: conflict-free under the row & 7 swizzle; round 2 read chunks 2q, 2q + 1: a 2-way bank conflict on every ds_read_b128)
+        const uint4_t lo = *reinterpret_cast<const uint4_t *>(base + row * 128 + ((q ^ (row & 7)) << 4));
+        const uint4_t hi = *reinterpret_cast<const uint4_t *>(base + row * 128 + (((4 + q) ^ (row & 7)) << 4));
         return mid_intx8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
     };
 

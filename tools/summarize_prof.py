@@ -8,9 +8,10 @@
       for wide coalesced streaming reads, MI355X_MICROARCH.md HBM section)
   python tools/summarize_prof.py sq     <pmc_dir> <out.csv> "<command line>" [kernel substring ...]
       per-kernel averages of every SQ counter of one --pmc pass, plus the derived ratios (MFMA busy, waits, LDS conflicts)
-  python tools/summarize_prof.py roofline <out.json> <key> <trace_dir> <kernel substring> <grid or 0> <stats csv> [<pmc json>]
+  python tools/summarize_prof.py roofline <out.json> <key> <trace_dir> <kernel substring> <grid or 0> <stats csv> [<fetch_dir> <write_dir>]
       adds/replaces entry <key> of the JSON bench.py reads for its *_rocprof_trace fractions: the kernel's average duration
-      in the kernel trace (and its PMC HBM bytes per launch)
+      in the kernel trace and, from the two PMC pass directories, its HBM bytes per launch -- only from counter rows of exactly the
+      same kernel name and grid (anything else is refused)
 """
 import csv, glob, json, os, sys
 from collections import defaultdict
@@ -115,33 +116,49 @@ def sq(d, out, cmd, subs):
     print("wrote", out)
 
 
-def roofline(out_json, key, d, kernel_sub, grid, stats_csv, pmc_json=None):
-    durs = []
+def roofline(out_json, key, d, kernel_sub, grid, stats_csv, dfetch=None, dwrite=None):
+    """entry <key>: the kernel's average duration in the kernel trace of <d>; kernel = the one whose demangled name contains
+    <kernel_sub>, at grid <grid> (threads; 0 = the grid with the largest total time among the matches).  With the two PMC pass
+    directories, `hbm_bytes_per_launch` is taken from the rows of EXACTLY that kernel name and grid -- a counter pass of another
+    instantiation or grid is refused (round 2 carried round-1 counters of a different GEMV instantiation in this field)."""
+    by = defaultdict(list)
     with open(find(d, "kernel_trace.csv")) as f:
         for r in csv.DictReader(f):
             if kernel_sub in r["Kernel_Name"]:
                 g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
-                if int(grid) in (0, g):
-                    durs.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-                    name = r["Kernel_Name"]
-    if not durs:
+                by[(r["Kernel_Name"], g)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    cand = {k: v for k, v in by.items() if int(grid) in (0, k[1])}
+    if not cand:
         raise SystemExit("kernel %s (grid %s) not in %s" % (kernel_sub, grid, d))
+    name, g = max(cand, key=lambda k: sum(cand[k]))
+    durs = cand[(name, g)]
     try:
         with open(out_json) as f:
             data = json.load(f)
     except (OSError, ValueError):
         data = {}
-    e = dict(kernel=short(name), grid=int(grid), calls=len(durs), avg_us=round(sum(durs) / len(durs) / 1e3, 3),
+    e = dict(kernel=short(name), grid=g, calls=len(durs), avg_us=round(sum(durs) / len(durs) / 1e3, 3),
              source="%s (rocprofv3 --kernel-trace, eager launches)" % stats_csv)
-    if pmc_json:
-        with open(pmc_json) as f:
-            pj = json.load(f)
-        e["hbm_bytes_per_launch"] = round(pj["hbm_bytes_per_launch"])
-        e["traffic_source"] = pj["source"]
+    if dfetch and dwrite:
+        def collect(dd, counter):
+            vals = []
+            with open(find(dd, "counter_collection.csv")) as f:
+                for r in csv.DictReader(f):
+                    if r["Counter_Name"] == counter and r["Kernel_Name"] == name and int(r["Grid_Size"]) == g:
+                        vals.append(float(r["Counter_Value"]))
+            return vals
+        fe, wr = collect(dfetch, "FETCH_SIZE"), collect(dwrite, "WRITE_SIZE")
+        if not fe or not wr:
+            raise SystemExit("REFUSED: no FETCH_SIZE / WRITE_SIZE rows for exactly kernel %s grid %d in %s / %s -- traffic of another "
+                             "instantiation or grid is not attached" % (short(name), g, dfetch, dwrite))
+        rd, wb = 2.0 * sum(fe) / len(fe) * 1024.0, sum(wr) / len(wr) * 1024.0
+        e["hbm_bytes_per_launch"] = round(rd + wb)
+        e["hbm_read_bytes"], e["hbm_write_bytes"] = round(rd), round(wb)
+        e["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of the same command (%d / %d launches of this kernel and grid; KiB units, FETCH_SIZE x2 gfx950 wide-read correction)" % (len(fe), len(wr))
     data[key] = e
     with open(out_json, "w") as f:
         json.dump(data, f, indent=1, sort_keys=True)
-    print("wrote", out_json, key, e["avg_us"], "us x", len(durs))
+    print("wrote", out_json, key, e["avg_us"], "us x", len(durs), "grid", g, "hbm", e.get("hbm_bytes_per_launch"))
 
 
 if __name__ == "__main__":
@@ -150,6 +167,6 @@ if __name__ == "__main__":
     elif sys.argv[1] == "sq":
         sq(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5:])
     elif sys.argv[1] == "roofline":
-        roofline(*sys.argv[2:9])
+        roofline(*sys.argv[2:10])
     else:
         pmc(*sys.argv[2:8])
