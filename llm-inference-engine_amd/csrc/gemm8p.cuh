@@ -167,6 +167,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void *__restrict__ Xv
     constexpr unsigned WKT_BYTES = WQ ? 64 : 128;   // bytes of a weight row per k-tile
     const unsigned char *xbase = X + static_cast<size_t>(m0) * row_bytes;   // wave-uniform bases; the per-lane part is 32-bit
     const unsigned char *wbase = W + static_cast<size_t>(n0) * wrow_bytes;
+    // the two DMA bases live in scalar registers from here on: no VALU producer (v_readfirstlane / v_readlane of a spill) can sit
+    // within the 5 wait states in front of a global_load_lds that reads them (g8_dma16 carries only `s_nop 0`)
+    asm volatile("" : "+s"(xbase), "+s"(wbase));
     typedef __attribute__((address_space(3))) void *lptr_t;
     const unsigned lds_addr = static_cast<unsigned>(reinterpret_cast<size_t>((lptr_t)lds));   // LDS byte address of the image
     unsigned voff[4][2], ldst[4][2];
@@ -421,6 +424,7 @@ __global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict
     const size_t wrow_bytes = WQ ? static_cast<size_t>(K) : row_bytes;
     constexpr unsigned WKT_BYTES = WQ ? 64 : 128;   // bytes of a weight row per k-tile
     const unsigned char *xbase = X + static_cast<size_t>(m0) * row_bytes, *wbase = W + static_cast<size_t>(n0) * wrow_bytes;
+    asm volatile("" : "+s"(xbase), "+s"(wbase));   // (scalar-resident DMA bases, as in gemm8p_kernel)
     typedef __attribute__((address_space(3))) void *lptr_t;
     const unsigned lds_addr = static_cast<unsigned>(reinterpret_cast<size_t>((lptr_t)lds));
     unsigned voff[3][2], ldst[2];

@@ -594,10 +594,25 @@ def test_sampling(llmie, dtype):
         sd, fd, od = dev(seq), dev(fin), torch.empty(bs, dtype=torch.int32, device=DEV)
         llmie.sampling(dev(tid), dev(tv, dtype), sd, fd, od, st, 2, V)
         eo, es, ef = orc.sampling(tid, tv, seq, fin, st, 2, V)
-        mism = (host(od) != eo)
+        got = host(od)
+        mism = (got != eo)
         assert mism.mean() <= 0.004, "device expf vs libm may flip a pick only on a threshold tie"
         assert np.array_equal(host(sd), es)
         assert np.array_equal(host(fd).astype(bool)[~mism], ef[~mism])
+        # ... and every pick that differs must BE such a tie: with the oracle's own uniform number u
+        # (the Philox stream is bit-identical on both sides) and the candidates' cumulative probabilities in float64, the device's
+        # and the oracle's candidates are neighbours and u sits within a few float32 ulps of the boundary between them
+        tvh = tv.astype(np.float16).astype(np.float64) if dtype == torch.float16 else tv.astype(np.float64)
+        e = np.exp(tvh - tvh[:, :1])
+        cum = np.cumsum(e, axis=1) / e.sum(axis=1, keepdims=True)
+        for b in np.nonzero(mism)[0]:
+            u = float(orc.lib().orc_uniform_philox(st, int(b)))
+            cand = tid[b] % V
+            gi, oi = np.nonzero(cand == got[b])[0], np.nonzero(cand == eo[b])[0]
+            assert gi.size and oi.size, "row %d: the device picked %d, not one of its candidates" % (b, got[b])
+            lo = min(gi.min(), oi.min())
+            assert abs(int(gi.min()) - int(oi.min())) == 1 and abs(u - cum[b, lo]) <= 4e-6, (
+                "row %d step %d: picks %d / %d are not a threshold tie (u %.9f, boundary %.9f)" % (b, st, got[b], eo[b], u, cum[b, lo]))
 
 
 def test_sampling_distribution(llmie):
