@@ -128,4 +128,20 @@ struct SlabScale {
     }
 };
 
+// ---- int8 weight tiles in LDS (gemm8p.cuh WQ form, gemm_mid.cuh int8 form): 64-byte rows, 16-byte slot c of row r holds source chunk
+// c ^ ((r >> 2) & 3); lane (r, q) multiplies k = 32 s + 8 q .. + 7 in k-step s = bytes [32 s + 8 q, + 8) of its row, one ds_read_b64;
+// de-quantisation in registers: byte ^ 0x80 under the fp16 exponent 0x64 is 1152 + w, a packed subtract of 1152 leaves w exactly
+__device__ __forceinline__ unsigned g8_q8_slot(int row, int chunk) { return static_cast<unsigned>((chunk ^ (row >> 2)) & 3); }
+// byte offset, inside its 64-byte row, of the 8 weights lane (r, q) multiplies in k-step s
+__device__ __forceinline__ unsigned g8_q8_piece(int r, int q, int s) { return (g8_q8_slot(r, 2 * s + (q >> 1)) << 4) + 8u * (q & 1); }
+__device__ __forceinline__ half8_t g8_dequant8(const uint2 w) {
+    const half2_t off = {static_cast<half_t>(1152.f), static_cast<half_t>(1152.f)};
+    const unsigned v0 = w.x ^ 0x80808080u, v1 = w.y ^ 0x80808080u;
+    const half2_t h0 = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(0x64646464u, v0, 0x04010400u)) - off;   // {0x64, b1, 0x64, b0}
+    const half2_t h1 = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(0x64646464u, v0, 0x04030402u)) - off;   // {0x64, b3, 0x64, b2}
+    const half2_t h2 = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(0x64646464u, v1, 0x04010400u)) - off;
+    const half2_t h3 = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(0x64646464u, v1, 0x04030402u)) - off;
+    return half8_t{h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
+}
+
 }  // namespace llmie

@@ -66,18 +66,6 @@ template <bool FP8> __device__ __forceinline__ void g8_mma(floatx4 &acc, const G
 // kernels compute.  LDS image of a B half: 128 rows x 64 B; the 16-byte slot c of row r holds source chunk c ^ ((r >> 2) & 3)
 // (applied on the DMA source address): the 32 lanes of a ds_read_b64 half-wave (16 rows x 2 values of q) then hit 32 different
 // 8-byte bank pairs.
-__device__ __forceinline__ unsigned g8_q8_slot(int row, int chunk) { return static_cast<unsigned>((chunk ^ (row >> 2)) & 3); }
-// byte offset, inside its 64-byte row, of the 8 weights lane (r, q) multiplies in k-step s
-__device__ __forceinline__ unsigned g8_q8_piece(int r, int q, int s) { return (g8_q8_slot(r, 2 * s + (q >> 1)) << 4) + 8u * (q & 1); }
-__device__ __forceinline__ half8_t g8_dequant8(const uint2 w) {
-    const half2_t off = {static_cast<half_t>(1152.f), static_cast<half_t>(1152.f)};
-    const unsigned v0 = w.x ^ 0x80808080u, v1 = w.y ^ 0x80808080u;
-    const half2_t h0 = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(0x64646464u, v0, 0x04010400u)) - off;   // {0x64, b1, 0x64, b0}
-    const half2_t h1 = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(0x64646464u, v0, 0x04030402u)) - off;   // {0x64, b3, 0x64, b2}
-    const half2_t h2 = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(0x64646464u, v1, 0x04010400u)) - off;
-    const half2_t h3 = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(0x64646464u, v1, 0x04030402u)) - off;
-    return half8_t{h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
-}
 // p = the lane's row in the LDS image; off0 / off1 = g8_q8_piece of the two k-steps
 __device__ __forceinline__ void g8_read_q8(G8Frag<false> &f, const unsigned char *p, unsigned off0, unsigned off1) {
     const uint2 w0 = *reinterpret_cast<const uint2 *>(p + off0), w1 = *reinterpret_cast<const uint2 *>(p + off1);

@@ -21,16 +21,26 @@ namespace llmie {
 
 typedef int mid_intx8 __attribute__((ext_vector_type(8)));
 
-template <bool FP8, int WN, int NS, int XR = 128>
+// WQ = 8 (round 3): W is int8 [N, K] under fp16 activations (decode batches of 33..128 sequences and short prefills of int8 engines:
+// the 64-row skinny kernel that served them streamed at 2.2-2.4 TB/s at 128 rows -- bench r03: int8 128-token prefill 18.1k tok/s
+// against 27.1k for fp16).  The weight tile travels as RAW bytes (64 B per row and 64-deep k-tile: half the DMA bytes, 16 rows per
+// wave instruction), a lane fetches its 8 weights of a k-step with one ds_read_b64 and de-quantises them in registers
+// (device_utils.cuh, g8_*); the slabs hold unscaled sums, the consumers apply the row scales as for the skinny kernel's slabs.
+template <bool FP8, int WN, int NS, int XR = 128, int WQ = 0>
 __global__ __launch_bounds__(512) void mid_splitk_kernel(const void *__restrict__ Xv, const void *__restrict__ Wv,
                                                          float *__restrict__ slab, int M, int N, int K, int KS, int kt_per_slice) {
+    static_assert(WQ == 0 || (WQ == 8 && !FP8), "int8 weights under fp16 activations");
     constexpr int ES = FP8 ? 1 : 2;   // bytes per element
     constexpr int BK = 128 / ES;      // k per tile: rows of 128 bytes either way
     // XR = activation rows staged per k-tile: 128, or 64 for M <= 64 (half the X tile: a 4th stage fits the 160 KiB and
     // three k-tiles of weights stay in flight per CU)
-    constexpr int X_BYTES = XR * 128, W_BYTES = 64 * WN * 128, STAGE_BYTES = X_BYTES + W_BYTES;
+    constexpr int WROW = WQ ? 64 : 128;   // bytes of a weight row per k-tile
     constexpr int X_INSTR = XR / 64;  // LDS-DMA instructions per wave for the X tile (8 rows each)
-    constexpr int IPT = X_INSTR + WN; // LDS-DMA instructions per wave per k-tile
+    // ... for the W tile: 8 rows of 128 B per instruction, or (int8) 16 rows of 64 B -- 4 WN pieces over the 8 waves; at WN = 3 every
+    // wave still issues two (the counted waits are per-wave immediates): the last four pieces re-fetch clamped rows into padding
+    constexpr int W_INSTR = WQ ? (4 * WN + 7) / 8 : WN;
+    constexpr int X_BYTES = XR * 128, W_BYTES = WQ ? W_INSTR * 8 * 1024 : 64 * WN * WROW, STAGE_BYTES = X_BYTES + W_BYTES;
+    constexpr int IPT = X_INSTR + W_INSTR; // LDS-DMA instructions per wave per k-tile
     constexpr int MI = XR / 32;       // 16-row activation tiles per wave (wave grid 2 x 4)
     static_assert(XR == 128 || XR == 64, "activation rows per stage");
     static_assert(WN >= 2 && WN <= 4, "128, 192 or 256 weight rows per workgroup");
@@ -48,13 +58,20 @@ __global__ __launch_bounds__(512) void mid_splitk_kernel(const void *__restrict_
     // DMA plan (gemm256.cuh): half h, instruction i: this wave fills rows (i*8 + wave)*8 .. +8; lane -> row + lane/8,
     // LDS slot lane%8 receives source chunk slot ^ (row & 7)
     // X: instruction i (< X_INSTR) fills X rows (i*8 + wave)*8 .. +8; W: instruction i (< WN) fills W rows (i*8 + wave)*8 .. +8
-    const unsigned char *xsrc[X_INSTR], *wsrc[WN];
+    const unsigned char *xsrc[X_INSTR], *wsrc[W_INSTR];
 #pragma unroll
-    for (int i = 0; i < (X_INSTR > WN ? X_INSTR : WN); ++i) {
+    for (int i = 0; i < (X_INSTR > W_INSTR ? X_INSTR : W_INSTR); ++i) {
         const int row = (i * 8 + wave) * 8 + (lane >> 3), slot = lane & 7, chunk = slot ^ (row & 7);
         if (i < X_INSTR)   // clamped rows are never stored
             xsrc[i] = X + (static_cast<size_t>(min(min(row, XR - 1), M - 1)) * K + static_cast<size_t>(kt0) * BK) * ES + chunk * 16;
-        if (i < WN) wsrc[i] = W + (static_cast<size_t>(min(n0 + row, N - 1)) * K + static_cast<size_t>(kt0) * BK) * ES + chunk * 16;
+        if constexpr (WQ != 0) {   // int8: 16 rows x 64 B per instruction; slot c of row r <- source chunk c ^ ((r >> 2) & 3)
+            if (i < W_INSTR) {
+                const int wrow = min((i * 8 + wave) * 16 + (lane >> 2), 64 * WN - 1);   // (WN = 3: pieces 12..15 are padding)
+                wsrc[i] = W + static_cast<size_t>(min(n0 + wrow, N - 1)) * K + static_cast<size_t>(kt0) * 64 + g8_q8_slot(wrow, lane & 3) * 16;
+            }
+        } else {
+            if (i < W_INSTR) wsrc[i] = W + (static_cast<size_t>(min(n0 + row, N - 1)) * K + static_cast<size_t>(kt0) * BK) * ES + chunk * 16;
+        }
     }
     // Workgroups of one K slice run in lock step and a k-tile of 128-byte row pieces at an 8 KiB row pitch lands in ONE L2
     // channel: every workgroup starts its slice at a different k-tile (sum order is irrelevant: fp32 partials), so that the
@@ -68,8 +85,8 @@ __global__ __launch_bounds__(512) void mid_splitk_kernel(const void *__restrict_
         for (int i = 0; i < X_INSTR; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[i] + static_cast<size_t>(t) * 128), (lptr_t)(lds + stage * STAGE_BYTES + (i * 8 + wave) * 1024), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < WN; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + static_cast<size_t>(t) * 128), (lptr_t)(lds + stage * STAGE_BYTES + X_BYTES + (i * 8 + wave) * 1024), 16, 0, 0);
+        for (int i = 0; i < W_INSTR; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + static_cast<size_t>(t) * WROW), (lptr_t)(lds + stage * STAGE_BYTES + X_BYTES + (i * 8 + wave) * 1024), 16, 0, 0);
     };
 
     floatx4 acc[MI][WN];
@@ -118,7 +135,12 @@ __global__ __launch_bounds__(512) void mid_splitk_kernel(const void *__restrict_
             for (int s = 0; s < 2; ++s) {
                 half8_t bf[WN], af[MI];
 #pragma unroll
-                for (int j = 0; j < WN; ++j) bf[j] = frag(bb, b_row0 + j * 16, s * 4 + q);
+                for (int j = 0; j < WN; ++j) {
+                    if constexpr (WQ != 0)   // (b_row0 + 16 j) >> 2 & 3 == r >> 2 & 3: the piece offset is per lane
+                        bf[j] = g8_dequant8(*reinterpret_cast<const uint2 *>(bb + (b_row0 + j * 16) * 64 + g8_q8_piece(r, q, s)));
+                    else
+                        bf[j] = frag(bb, b_row0 + j * 16, s * 4 + q);
+                }
 #pragma unroll
                 for (int i = 0; i < MI; ++i) af[i] = frag(ab, a_row0 + i * 16, s * 4 + q);
                 // D[n-row, m-col]: W as the MFMA A operand -> 4 consecutive n per lane (16-byte fp32 stores)

@@ -221,7 +221,8 @@ static SplitKPlan splitk_plan(int wbits, int M, int K, int N) {
     // 64 < M <= 128, fp16 or e4m3 operands: 128-row LDS-DMA kernel; 32 < M <= 64: its 64-row form (measured fp16 M=64:
     // gate/up 55.6 -> 44.7 us, qkv 33.0 -> 29.8, down 29.2 -> 25.8 against the skinny kernel; about equal at M = 32)
     const bool mid64 = M <= 64 && M >= 33;
-    if ((wbits == 16 || wbits == WF_FP8) && (M >= 65 || mid64) && K % 128 == 0 && N >= 128) {
+    // (int8 weights, round 3: the same kernel with raw int8 weight tiles; 128 or 256 weight rows per workgroup, from 65 rows)
+    if ((wbits == 16 || wbits == WF_FP8 || (wbits == 8 && M >= 65)) && (M >= 65 || mid64) && K % 128 == 0 && N >= 128) {
         const bool fp8 = wbits == WF_FP8;
         p.form = mid64 ? 2 : 1;
         const int KT = K / (fp8 ? 128 : 64);
@@ -301,7 +302,18 @@ int linear_splitk_partial(int wbits, const void *x, const void *W, int M, int K,
         }();
         (void)attr_set;
         const dim3 mgrid(mtiles * ks);
-        if (mid64) {
+        if (wbits == 8) {   // int8 weights: stage = 16 KiB of activations + 16 KiB (192 / 256 rows) or 8 KiB (128 rows) of weights
+            static const bool attrq = [] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<false, 4, 5, 128, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32768);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<false, 3, 5, 128, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32768);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<false, 2, 6, 128, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 24576);
+                return true;
+            }();
+            (void)attrq;
+            if (wn == 4) mid_splitk_kernel<false, 4, 5, 128, 8><<<mgrid, 512, 5 * 32768, st>>>(x, W, mslab, M, N, K, ks, per);
+            else if (wn == 3) mid_splitk_kernel<false, 3, 5, 128, 8><<<mgrid, 512, 5 * 32768, st>>>(x, W, mslab, M, N, K, ks, per);
+            else mid_splitk_kernel<false, 2, 6, 128, 8><<<mgrid, 512, 6 * 24576, st>>>(x, W, mslab, M, N, K, ks, per);
+        } else if (mid64) {
             static const bool attr64 = [] {   // once per process, thread-safe (function-local static initialisation)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<false, 4, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 40960);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mid_splitk_kernel<true, 4, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 40960);
