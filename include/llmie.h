@@ -348,6 +348,9 @@ typedef struct {
  *                             one matrix at a time into its workspace.  An int8 Llama-2-7B decoder is then resident at ~6.5 GB
  *                             instead of ~13 GB.
  * llmie_decoder_resident_weight_bytes: bytes of layer-matrix storage (row-major matrices that must stay + images) of a config. */
+/* llmie_decoder_repack (ABI 3): the weights were updated in place, or -- for a packed-only engine -- are to be replaced: rebuild
+ * the images from `layers` (row-major matrices in the engine's format; their scale / bias / gamma pointers replace the ones given
+ * at create).  The pack kernels are enqueued on `stream`. */
 #define LLMIE_DEC_NO_PACKED_COPY 1
 #define LLMIE_DEC_PACKED_ONLY 2
 size_t llmie_decoder_resident_weight_bytes(const llmie_decoder_config *cfg);
@@ -361,6 +364,7 @@ llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg,
                                     const llmie_layer_weights *layers,
                                     void *workspace, size_t workspace_bytes);
 void llmie_decoder_destroy(llmie_decoder *dec);
+int llmie_decoder_repack(llmie_decoder *dec, const llmie_layer_weights *layers, llmie_stream stream);   /* see LLMIE_DEC_* above */
 
 /* One decode step through all layers, in place semantics of LlamaSelfDecoder::forward:
  * hidden_in[bs,H] -> hidden_out[bs,H] (may alias).  Caches [L, batch, kvh, max_seq, hs].

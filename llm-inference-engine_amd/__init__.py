@@ -100,6 +100,7 @@ _SIGS = {
     "llmie_decoder_profile_end": [_vp, _vp, _vp, _vp],
     "llmie_decoder_status": [_vp, _vp],
     "llmie_decoder_resident_weight_bytes": [_vp],
+    "llmie_decoder_repack": [_vp, _vp, _vp],
     "llmie_decoder_debug_stamps": [_vp, _vp],
     "llmie_abi_version": [],
     "llmie_last_error": [],
@@ -485,6 +486,14 @@ class Decoder:
         n = (C.c_int * len(self.OPS))()
         _check(lib().llmie_decoder_profile_end(self.handle, _st(), ms, n), "decoder_profile_end")
         return {op: (ms[i], n[i]) for i, op in enumerate(self.OPS)}
+
+    def repack(self, layers):
+        """rebuild the tile-packed weight images from `layers` (same structure as at construction)"""
+        arr = (LayerWeights * len(layers))()
+        for i, lw in enumerate(layers):
+            arr[i] = LayerWeights(_p(lw["attn_norm"]), _mat(lw["qkv"]), _mat(lw["o"]), _p(lw["ffn_norm"]), _mat(lw["gate_up"]), _mat(lw["down"]))
+        _check(lib().llmie_decoder_repack(self.handle, arr, _st()), "decoder_repack")
+        self._keep = layers
 
     def debug_stamps(self, buf):
         """diagnostic: chain launches write their phase-edge timestamps into buf (uint64 [256, 16] on the device); None disarms"""

@@ -49,6 +49,7 @@ struct llmie_decoder {
     float *pk_slab = nullptr;
     size_t pk_slab_floats = 0;
     // persistent chain launches of the packed path: one zeroed block of barrier counters per layer, one device error word
+    unsigned char *pk_base = nullptr;   // first byte of the packed images (the workspace area carved for them)
     unsigned *pk_sync = nullptr, *pk_err = nullptr;
     unsigned long long *pk_stamps = nullptr;   // diagnostic: phase-edge timestamps of the LAST chain launch of a step
     // paged KV cache of the current llmie_decoder_forward_paged call (null: dense caches)
@@ -236,6 +237,49 @@ extern "C" size_t llmie_decoder_workspace_bytes(const llmie_decoder_config *cfg)
     return carve(cfg, offs);
 }
 
+// (re)build the tile-packed images of every layer from row-major matrices (create; llmie_decoder_repack)
+static int pack_layers(llmie_decoder *d, const llmie_layer_weights *layers, hipStream_t st) {
+    const llmie_decoder_config *cfg = &d->cfg;
+    const PackedCarve pc = packed_carve(cfg, d->pk_wf);
+    unsigned char *pb = d->pk_base;
+    const int H = d->H, QKV = d->QKV, I = d->I;
+    d->packed.resize(cfg->num_layers);
+    int prc = LLMIE_OK;
+    for (int l = 0; l < cfg->num_layers && prc == LLMIE_OK; ++l) {
+        unsigned char *q = pb + static_cast<size_t>(l) * pc.layer_bytes;
+        unsigned char *po = q + pc.per_layer[0], *pg = po + pc.per_layer[1], *pd = pg + pc.per_layer[2];
+        const llmie_layer_weights &w = layers[l];
+        const bool i4 = d->pk_wf == PKF_I4;
+        unsigned char *sq = q + align_up(pk_packed_bytes(d->pk_wf, QKV, H, 0)), *so = po + align_up(pk_packed_bytes(d->pk_wf, H, H, 0));
+        unsigned char *sg = pg + align_up(pk_packed_bytes(d->pk_wf, 2 * I, H, 1)), *sd = pd + align_up(pk_packed_bytes(d->pk_wf, H, I, 0));
+        prc = pk_pack(d->pk_wf, w.qkv.data, i4 ? w.qkv.scale : nullptr, q, i4 ? sq : nullptr, QKV, H, 0, st);
+        if (!prc) prc = pk_pack(d->pk_wf, w.o.data, i4 ? w.o.scale : nullptr, po, i4 ? so : nullptr, H, H, 0, st);
+        if (!prc) prc = pk_pack(d->pk_wf, w.gate_up.data, i4 ? w.gate_up.scale : nullptr, pg, i4 ? sg : nullptr, 2 * I, H, 1, st);
+        if (!prc) prc = pk_pack(d->pk_wf, w.down.data, i4 ? w.down.scale : nullptr, pd, i4 ? sd : nullptr, H, I, 0, st);
+        d->packed[l] = llmie_decoder::PackedLayer{q, po, pg, pd, {i4 ? sq : nullptr, i4 ? so : nullptr, i4 ? sg : nullptr, i4 ? sd : nullptr}};
+    }
+    return prc;
+}
+
+// Weights changed in place (or, for a LLMIE_DEC_PACKED_ONLY engine, new weights altogether): rebuild the tile-packed images from
+// `layers` (row-major matrices in the engine's format; scale / bias / gamma pointers replace the ones given at create).  Enqueued
+// on `stream`; engines without images just take the new pointers.
+extern "C" int llmie_decoder_repack(llmie_decoder *dec, const llmie_layer_weights *layers, llmie_stream stream) {
+    LLMIE_REQUIRE(dec && layers, "decoder_repack: NULL pointer");
+    for (int l = 0; l < dec->cfg.num_layers; ++l) {
+        const llmie_layer_weights &w = layers[l];
+        LLMIE_REQUIRE(w.attn_norm_gamma && w.ffn_norm_gamma && w.qkv.data && w.o.data && w.gate_up.data && w.down.data,
+                      "decoder_repack: layer %d has a NULL weight", l);
+    }
+    int rc = LLMIE_OK;
+    if (dec->pk_wf) rc = pack_layers(dec, layers, as_stream(stream));
+    if (rc) return rc;
+    dec->layers.assign(layers, layers + dec->cfg.num_layers);
+    if (dec->packed_only)
+        for (llmie_layer_weights &w : dec->layers) w.qkv.data = w.o.data = w.gate_up.data = w.down.data = nullptr;
+    return LLMIE_OK;
+}
+
 extern "C" size_t llmie_decoder_resident_weight_bytes(const llmie_decoder_config *cfg) {
     if (!config_ok(cfg)) return 0;
     const size_t H = static_cast<size_t>(cfg->head_num) * cfg->head_size, QKV = static_cast<size_t>(cfg->head_num + 2 * cfg->kv_head_num) * cfg->head_size;
@@ -335,22 +379,8 @@ extern "C" llmie_decoder *llmie_decoder_create(const llmie_decoder_config *cfg, 
         // compute path); the row-major originals stay in use for batch <= gemv_max (GEMV) and for prefill
         const PackedCarve pc = packed_carve(cfg, d->pk_wf);
         unsigned char *pb = reinterpret_cast<unsigned char *>(base + offs[10]);
-        const int H = d->H, QKV = d->QKV, I = d->I;
-        d->packed.resize(cfg->num_layers);
-        int prc = LLMIE_OK;
-        for (int l = 0; l < cfg->num_layers && prc == LLMIE_OK; ++l) {
-            unsigned char *q = pb + static_cast<size_t>(l) * pc.layer_bytes;
-            unsigned char *po = q + pc.per_layer[0], *pg = po + pc.per_layer[1], *pd = pg + pc.per_layer[2];
-            const llmie_layer_weights &w = layers[l];
-            const bool i4 = d->pk_wf == PKF_I4;
-            unsigned char *sq = q + align_up(pk_packed_bytes(d->pk_wf, QKV, H, 0)), *so = po + align_up(pk_packed_bytes(d->pk_wf, H, H, 0));
-            unsigned char *sg = pg + align_up(pk_packed_bytes(d->pk_wf, 2 * I, H, 1)), *sd = pd + align_up(pk_packed_bytes(d->pk_wf, H, I, 0));
-            prc = pk_pack(d->pk_wf, w.qkv.data, i4 ? w.qkv.scale : nullptr, q, i4 ? sq : nullptr, QKV, H, 0, nullptr);
-            if (!prc) prc = pk_pack(d->pk_wf, w.o.data, i4 ? w.o.scale : nullptr, po, i4 ? so : nullptr, H, H, 0, nullptr);
-            if (!prc) prc = pk_pack(d->pk_wf, w.gate_up.data, i4 ? w.gate_up.scale : nullptr, pg, i4 ? sg : nullptr, 2 * I, H, 1, nullptr);
-            if (!prc) prc = pk_pack(d->pk_wf, w.down.data, i4 ? w.down.scale : nullptr, pd, i4 ? sd : nullptr, H, I, 0, nullptr);
-            d->packed[l] = llmie_decoder::PackedLayer{q, po, pg, pd, {i4 ? sq : nullptr, i4 ? so : nullptr, i4 ? sg : nullptr, i4 ? sd : nullptr}};
-        }
+        d->pk_base = pb;
+        const int prc = pack_layers(d, layers, nullptr);
         unsigned char *tail = pb + pc.layer_bytes * cfg->num_layers;
         d->hx = reinterpret_cast<half_t *>(tail);
         d->actx = reinterpret_cast<half_t *>(tail + pc.hx);

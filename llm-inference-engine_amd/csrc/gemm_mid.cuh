@@ -21,6 +21,13 @@ namespace llmie {
 
 typedef int mid_intx8 __attribute__((ext_vector_type(8)));
 
+#ifdef MID_STAMPS   // diagnostic build only (tools/micro/mid_probe.hip): where a workgroup's time goes; never defined in the product build
+__device__ unsigned long long mid_stamp_buf[1024 * 8];
+#define MID_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) mid_stamp_buf[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MID_STAMP(i) do { } while (0)
+#endif
+
 // WQ = 8 (round 3): W is int8 [N, K] under fp16 activations (decode batches of 33..128 sequences and short prefills of int8 engines:
 // the 64-row skinny kernel that served them streamed at 2.2-2.4 TB/s at 128 rows -- bench r03: int8 128-token prefill 18.1k tok/s
 // against 27.1k for fp16).  The weight tile travels as RAW bytes (64 B per row and 64-deep k-tile: half the DMA bytes, 16 rows per
@@ -107,15 +114,19 @@ __global__ __launch_bounds__(512) void mid_splitk_kernel(const void *__restrict_
         return mid_intx8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
     };
 
+    MID_STAMP(0);
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
         if (t < nk) dma_tile(t, t);
+    MID_STAMP(1);
     int stage = 0, fill = NS - 1;  // fill = stage that receives tile kt + NS - 1
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt has landed when at most the (NS - 2) younger tiles of this wave are outstanding
         if (kt + NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * IPT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // every wave's part of tile kt landed; every wave is done with stage `fill` (tile kt - 1)
+        if (kt == 0) MID_STAMP(2);
+        if (kt == nk / 2) MID_STAMP(3);
         if (kt + NS - 1 < nk) dma_tile(kt + NS - 1, fill);
         const unsigned char *ab = a_base + stage * STAGE_BYTES, *bb = b_base + stage * STAGE_BYTES;
         if constexpr (FP8) {
@@ -153,6 +164,7 @@ __global__ __launch_bounds__(512) void mid_splitk_kernel(const void *__restrict_
         stage = stage + 1 == NS ? 0 : stage + 1;
         fill = fill + 1 == NS ? 0 : fill + 1;
     }
+    MID_STAMP(4);
     // acc[i][j]: lane holds rows m = wr*(XR/2) + i*16 + r, columns n0 + wcol + j*16 + 4q + e
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -171,6 +183,7 @@ __global__ __launch_bounds__(512) void mid_splitk_kernel(const void *__restrict_
             }
         }
     }
+    MID_STAMP(5);
 }
 
 }  // namespace llmie

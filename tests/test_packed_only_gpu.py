@@ -80,7 +80,19 @@ def test_packed_only_engine_runs_without_the_row_major_weights(llmie, wfmt):
         assert bool((d <= 3e-2 + 3e-2 * a.abs()).all()), "prefill %d: max diff %g" % (T, d.max().item())
         assert ((a - b).norm() / a.norm()).item() < 5e-3
         assert (k1.float() - k2.float()).abs().max().item() <= 2e-2
+    # llmie_decoder_repack: new weights into the same engine -> what a fresh engine on those weights computes
+    layers2 = _layers(llmie, np.random.default_rng(58), wfmt)
+    ref2 = llmie.Decoder(cfg, layers2)
+    po.repack([{k: (dict(v, data=v["data"].clone()) if isinstance(v, dict) else v) for k, v in lw.items()} for lw in layers2])
+    bs = 17
+    kc = (torch.randn((L, bs, NH, max_seq, HS), generator=g) * 0.5).to(DEV).to(F16)
+    vc = (torch.randn((L, bs, NH, max_seq, HS), generator=g) * 0.5).to(DEV).to(F16)
+    x = torch.randn((bs, H), generator=g).to(DEV).to(F16)
+    a = ref2.forward(x, torch.empty_like(x), kc.clone(), vc.clone(), 150)
+    b = po.forward(x, torch.empty_like(x), kc.clone(), vc.clone(), 150)
+    assert torch.equal(a, b), "repacked engine differs from a fresh engine on the new weights"
     ref.close()
+    ref2.close()
     po.close()
 
 
