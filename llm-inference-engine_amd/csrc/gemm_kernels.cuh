@@ -559,7 +559,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_mfma_f16_kernel(const half_t *
                                                                   const half_t *__restrict__ W,
                                                                   half_t *__restrict__ y, int M, int K,
                                                                   int N, const half_t *__restrict__ bias,
-                                                                  const half_t *__restrict__ residual) {
+                                                                  const half_t *residual) {
     __shared__ floatx4 red[NW][NT * MT][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(256) void generic_gemm_kernel(const T *__restrict__
                                                            T *__restrict__ C, int M, int N, int K,
                                                            size_t strideA, size_t strideB, size_t strideC,
                                                            const T *__restrict__ bias,
-                                                           const T *__restrict__ residual) {
+                                                           const T *residual) {
     __shared__ float As[16][64 + 1];
     __shared__ float Bs[16][64 + 1];
     A += blockIdx.z * strideA;

@@ -43,6 +43,9 @@ int splitk_rownorm(const SplitKSlabs &sk, const SlabScale &wscale, const half_t 
 bool rmsnorm_quant_eligible(int hidden);
 int rmsnorm_quant_f16(const half_t *x, half_t *resid, const half_t *bias, const half_t *gamma, float eps, int tokens, int hidden,
                       bool fused, uint8_t *xq, float *xscale, hipStream_t st);
+// out-of-place RMSNorm (x untouched): the prefill's residual stream stays in its own buffer; norm.hip
+bool rmsnorm_oop_eligible(int hidden);
+int rmsnorm_oop_f16(const half_t *x, half_t *y, const half_t *gamma, float eps, int tokens, int hidden, hipStream_t st);
 // per-token e4m3 quantisation of fp16 rows (scale amax/448); fp8_linear.hip
 int quantize_rows_fp8(const half_t *x, uint8_t *xq, float *xscale, int M, int K, hipStream_t st);
 int linear_splitk(int wbits, const half_t *x, const void *W, const half_t *scale, half_t *y, int M, int K, int N, int epi,

@@ -197,6 +197,54 @@ __global__ __launch_bounds__(256) void rmsnorm_generic_kernel(
             x[row + i] = from_f32<T>(to_f32(x[row + i]) * to_f32(gamma[i]) * inv);
 }
 
+// Out-of-place RMSNorm, fp16 (round 3, prefill): y = x * gamma * rsqrt(mean(x^2) + eps) with x left as it is -- the residual stream
+// stays un-normalised in its own buffer (the O / down projections add into it in their epilogues), so a norm moves 2 x |x| bytes
+// instead of the 3-4 x of rmsnorm.cu's "copy the residual out, normalise in place" form.  Same arithmetic per element as
+// rmsnorm_kernel (fp32 sum of squares of the fp16 values, one rounding).
+__global__ __launch_bounds__(256) void rmsnorm_oop_kernel(const half_t *__restrict__ x, half_t *__restrict__ y,
+                                                          const half_t *__restrict__ gamma, float eps, int hidden) {
+    constexpr int MAXV = 4;
+    __shared__ float red[4];
+    const int nvec = hidden / 8;
+    const size_t row = static_cast<size_t>(blockIdx.x) * hidden;
+    const half8_t *xv = reinterpret_cast<const half8_t *>(x + row);
+    half8_t *yv = reinterpret_cast<half8_t *>(y + row);
+    const half8_t *gv = reinterpret_cast<const half8_t *>(gamma);
+    half8_t keep[MAXV];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int i = threadIdx.x + j * 256;
+        if (i < nvec) {
+            keep[j] = xv[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += to_f32(keep[j][e]) * to_f32(keep[j][e]);
+        }
+    }
+    ss = block_sum<4>(ss, red);
+    const float inv = rsqrtf(ss / static_cast<float>(hidden) + eps);
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int i = threadIdx.x + j * 256;
+        if (i < nvec) {
+            const half8_t g = gv[i];
+            half8_t v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = from_f32<half_t>(to_f32(keep[j][e]) * to_f32(g[e]) * inv);
+            yv[i] = v;
+        }
+    }
+}
+bool rmsnorm_oop_eligible(int hidden) { return hidden % 8 == 0 && hidden / 8 <= 1024; }
+int rmsnorm_oop_f16(const half_t *x, half_t *y, const half_t *gamma, float eps, int tokens, int hidden, hipStream_t st) {
+    if (!rmsnorm_oop_eligible(hidden) || (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma)) % 16) {
+        set_error("rmsnorm (out of place): hidden %d / alignment not supported", hidden);
+        return LLMIE_ERR_UNSUPPORTED;
+    }
+    rmsnorm_oop_kernel<<<tokens, 256, 0, st>>>(x, y, gamma, eps, hidden);
+    return launch_status("rmsnorm(out of place)");
+}
+
 template <typename T, bool FUSED>
 static int launch_norm(T *x, T *resid, const T *bias, const T *gamma, float eps, int tokens,
                        int hidden, hipStream_t st) {
