@@ -128,6 +128,18 @@ struct SlabScale {
     }
 };
 
+// operands of the QKV projection's RoPE + KV-append epilogue (gemm256.cuh g256_store_qkv_rope; filled by the engine's prefill)
+struct QkvRopeArgs {           // layer-invariant; lives in device memory (prefill_token_table writes it once per prefill call)
+    void *k_cache, *v_cache;   // whole caches (all layers)
+    const int32_t *tok_b;      // [T] sequence of packed token t
+    const int32_t *tok_tpos;   // [T] cache position history + position of packed token t (< 0 or >= max_seq_len: not written)
+    const float2 *rope;        // [max_seq_len][64] (cos, sin)
+    const int32_t *table;      // paged cache: [batch, max_pages] or null
+    size_t layer_stride;       // elements of one layer's cache slab (dense: batch * kvh * max_seq * 128; paged: num_pages * kvh * 128 * 128)
+    int head_num, kv_head_num, max_seq_len, rotary_dim, max_pages, kv8;
+    float k_inv_scale, v_inv_scale;
+};
+
 // ---- int8 weight tiles in LDS (gemm8p.cuh WQ form, gemm_mid.cuh int8 form): 64-byte rows, 16-byte slot c of row r holds source chunk
 // c ^ ((r >> 2) & 3); lane (r, q) multiplies k = 32 s + 8 q .. + 7 in k-step s = bytes [32 s + 8 q, + 8) of its row, one ds_read_b64;
 // de-quantisation in registers: byte ^ 0x80 under the fp16 exponent 0x64 is 1152 + w, a packed subtract of 1152 leaves w exactly

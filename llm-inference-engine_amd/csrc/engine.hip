@@ -882,7 +882,7 @@ extern "C" int llmie_decoder_forward_paged(llmie_decoder *dec, const void *hidde
     return rc;
 }
 
-static size_t prefill_carve(const llmie_decoder_config *c, int T, int B, size_t *o /*[10]*/) {
+static size_t prefill_carve(const llmie_decoder_config *c, int T, int B, size_t *o /*[11]*/) {
     const size_t e = 2, H = static_cast<size_t>(c->head_num) * c->head_size;
     const size_t QKV = static_cast<size_t>(c->head_num + 2 * c->kv_head_num) * c->head_size, I = c->inter_size;
     Carve k;
@@ -909,12 +909,13 @@ static size_t prefill_carve(const llmie_decoder_config *c, int T, int B, size_t 
         }
     }
     o[9] = k.take(dq + 256);
+    o[10] = k.take(static_cast<size_t>(T) * 2 * sizeof(int32_t) + 256);   // (sequence, cache position) of every packed token + QkvRopeArgs
     return k.off;
 }
 
 extern "C" size_t llmie_decoder_prefill_workspace_bytes(const llmie_decoder_config *cfg, int max_tokens, int max_batch) {
     if (!config_ok(cfg) || max_tokens <= 0 || max_batch <= 0) return 0;
-    size_t o[10];
+    size_t o[11];
     return prefill_carve(cfg, max_tokens, max_batch, o);
 }
 
@@ -934,7 +935,7 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
     const int wqbits = c.wfmt == LLMIE_W_INT8 ? 8 : (c.wfmt == LLMIE_W_INT4 ? 4 : 0);
     if (c.dtype != LLMIE_F16 || (c.wfmt != LLMIE_W_F16 && !fp8 && !wqbits) || c.head_size != 128)
         LLMIE_UNSUPPORTED("decoder_prefill: fp16 activations + fp16 / int8 / int4 / fp8 weights + head_size 128 only (use the per-kernel path)");
-    size_t o[10];
+    size_t o[11];
     const size_t need = prefill_carve(&c, num_tokens, batch, o);
     if (workspace_bytes < need || reinterpret_cast<uintptr_t>(workspace) % 256) {
         set_error("decoder_prefill: workspace too small or unaligned (%zu < %zu)", workspace_bytes, need);
@@ -958,7 +959,9 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
     const size_t f8ws_bytes = fp8 ? llmie_linear_fp8_workspace_bytes(T, I > H ? I : H, 0) : 0;
     const SlabWs slabs{reinterpret_cast<float *>(base + o[8]), engine_slab_floats(&c, T < 192 ? T : 192)};
     void *deq = base + o[9];
-    const size_t deq_bytes = need - o[9];
+    const size_t deq_bytes = o[10] - o[9];
+    QkvRopeArgs *rope_args = (QkvRopeArgs *)(base + o[10]);   // (device copy of the fused QKV epilogue's operands)
+    int32_t *tok_b = (int32_t *)(base + o[10] + 256), *tok_tpos = tok_b + T;
     // y = x . W^T (+ residual) in the engine's weight format (fp8: per-token e4m3 activations, fp8 MFMA)
     auto proj = [&](const half_t *x, const llmie_matrix &w, half_t *y, int K, int N, const half_t *residual) -> int {
         if (wqbits)
@@ -972,6 +975,65 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
     // context_decoder.cpp:70: exclusive prefix of the lengths (padding offsets are a by-product nobody needs here);
     // the prefix kernel takes [batch, max_q_len] with max_q_len = ceil(T / batch) rows worth of scratch -> use 1 row of T
     if ((rc = llmie_cal_padding_offset(pad, cum, input_lengths, batch, (T + batch - 1) / batch, stream))) return rc;
+    // Round 3: RoPE + KV-cache append as the EPILOGUE of the QKV projection (context_attention.cpp:158-205 in one launch sequence;
+    // gemm8p.cuh ROPE forms): q is rotated on its way into the packed QKV buffer, k / v go straight to their cache slots and never
+    // travel through the buffer; bit-identical to projection + prefill_rope_append_kernel (same arithmetic on the fp16-rounded
+    // accumulator).  Prefill-sized T on the eight-phase kernels only; everything else keeps the two launches.
+    static const bool rope_fuse_off = getenv("LLMIE_NO_QKV_ROPE_FUSION") != nullptr;
+    const bool kv8 = c.kv_fmt == LLMIE_KV_FP8;
+    const float ksc = (kv8 && c.k_scale > 0.f) ? c.k_scale : 1.f, vsc = (kv8 && c.v_scale > 0.f) ? c.v_scale : 1.f;
+    bool rope_fusable = !rope_fuse_off && T >= kWqPrefillRows && !dec->packed_only && gemm256_fills(T, QKV);
+    if (rope_fusable) {
+        QkvRopeArgs ra{};
+        ra.k_cache = k_cache;
+        ra.v_cache = v_cache;
+        ra.rope = dec->rope_table;
+        ra.table = dec->page_table;
+        ra.layer_stride = dec->page_table ? static_cast<size_t>(dec->num_pages) * c.kv_head_num * 128 * c.head_size
+                                          : static_cast<size_t>(batch) * c.kv_head_num * c.max_seq_len * c.head_size;
+        ra.head_num = c.head_num;
+        ra.kv_head_num = c.kv_head_num;
+        ra.max_seq_len = c.max_seq_len;
+        ra.rotary_dim = c.rotary_dim;
+        ra.max_pages = dec->max_pages;
+        ra.kv8 = kv8 ? 1 : 0;
+        ra.k_inv_scale = 1.0f / ksc;
+        ra.v_inv_scale = 1.0f / vsc;
+        if ((rc = prefill_token_table(cum, history_lengths, batch, T, tok_b, tok_tpos, ra, rope_args, st))) return rc;
+    }
+    // kind: 0 = fp16 operands, 1 = e4m3 operands (xs = token scales), 8 = int8 weights
+    auto qkv_rope = [&](int l, const llmie_matrix &w, int kind, const void *x, const float *xs, const void *Wd, const void *wsc) -> int {
+        gemm256_qkv_rope_launch(kind, x, Wd, qkv, T, QKV, H, xs, static_cast<const float *>(wsc), static_cast<const half_t *>(w.bias), rope_args, l, st);
+        return launch_status("decoder_prefill(qkv + rope + append)");
+    };
+    // the QKV projection of fp16 / int8 / int4 engines; *fused = 1 when its epilogue did RoPE + the cache append
+    auto qkv_proj = [&](int l, const llmie_matrix &w, const half_t *x, int *fused) -> int {
+        *fused = 0;
+        if (rope_fusable && !fp8 && reinterpret_cast<uintptr_t>(w.bias) % 8 == 0) {
+            if (!wqbits && gemm256_qkv_rope_eligible(0, T, QKV, H, x, w.data, nullptr, qkv)) {
+                *fused = 1;
+                return qkv_rope(l, w, 0, x, nullptr, w.data, nullptr);
+            }
+            if (wqbits == 8 && g8p_w8_eligible(T, H, QKV, x, w.data, w.scale, qkv) && gemm256_qkv_rope_eligible(8, T, QKV, H, x, w.data, w.scale, qkv)) {
+                *fused = 1;
+                return qkv_rope(l, w, 8, x, nullptr, w.data, w.scale);
+            }
+            // int4 (and int8 shapes without the in-kernel form): the fp16 image of the matrix, as linear_wq takes it
+            if (wqbits && deq_bytes >= static_cast<size_t>(QKV) * H * sizeof(half_t) && H % 8 == 0 && reinterpret_cast<uintptr_t>(w.data) % 8 == 0 &&
+                (wqbits == 8 || (c.int4_group % 8 == 0 && H % c.int4_group == 0)) && gemm256_qkv_rope_eligible(0, T, QKV, H, x, deq, nullptr, qkv)) {
+                int rc2 = dequantize_weights_f16(wqbits, w.data, static_cast<const half_t *>(w.scale), static_cast<half_t *>(deq), QKV, H, c.int4_group, st);
+                if (rc2) return rc2;
+                *fused = 1;
+                return qkv_rope(l, w, 0, x, nullptr, deq, nullptr);
+            }
+        }
+        return proj(x, w, qkv, H, QKV, nullptr);
+    };
+    auto attention = [&](int l, const llmie_matrix &wqkv, int fused) -> int {
+        return prefill_attention_f16(qkv, (const half_t *)wqkv.bias, k_cache, v_cache, attn, cum, history_lengths, dec->rope_table, l, batch, T,
+                                     max_q_len, c.head_num, c.kv_head_num, c.head_size, c.max_seq_len, c.rotary_dim, st, kv8, ksc, vsc,
+                                     dec->page_table, dec->max_pages, dec->num_pages, fused);
+    };
     // Short prefills (<= 128 tokens, fp16 weights) are weight-stream bound like a decode batch: same launch fusion as the batch
     // decode path -- every projection leaves split-K slabs, the O and down slabs are consumed by the row kernel (reduction +
     // residual stream + the next RMSNorm), the gate/up slabs by the SwiGLU finalize: 9 launches per layer instead of 13.
@@ -1068,11 +1130,9 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
         for (int l = 0; l < c.num_layers; ++l) {
             const llmie_layer_weights &w = dec->layers[l];
             TIMED(LLMIE_OP_ATTN_NORM, rmsnorm_oop_f16(S, Nn, (const half_t *)w.attn_norm_gamma, c.rms_eps, T, H, st));
-            TIMED(LLMIE_OP_QKV_GEMM, proj(Nn, w.qkv, qkv, H, QKV, nullptr));
-            TIMED(LLMIE_OP_MHA, prefill_attention_f16(qkv, (const half_t *)w.qkv.bias, k_cache, v_cache, attn, cum, history_lengths,
-                                                      dec->rope_table, l, batch, T, max_q_len, c.head_num, c.kv_head_num, c.head_size,
-                                                      c.max_seq_len, c.rotary_dim, st, c.kv_fmt == LLMIE_KV_FP8, c.k_scale > 0.f ? c.k_scale : 1.f,
-                                                      c.v_scale > 0.f ? c.v_scale : 1.f, dec->page_table, dec->max_pages, dec->num_pages));
+            int fused;
+            TIMED(LLMIE_OP_QKV_GEMM, qkv_proj(l, w.qkv, Nn, &fused));
+            TIMED(LLMIE_OP_MHA, attention(l, w.qkv, fused));
             TIMED(LLMIE_OP_O_GEMM, proj(attn, w.o, S, H, H, S));
             TIMED(LLMIE_OP_FFN_NORM, rmsnorm_oop_f16(S, Nn, (const half_t *)w.ffn_norm_gamma, c.rms_eps, T, H, st));
             if (wqbits && (T < kWqPrefillRows || gemm256_swiglu_fills(T, 2 * I))) {
@@ -1090,19 +1150,22 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
     }
     for (int l = 0; l < c.num_layers; ++l) {
         const llmie_layer_weights &w = dec->layers[l];
+        int fused = 0;
         if (tiled_fp8(w.qkv, QKV)) {
             TIMED(LLMIE_OP_ATTN_NORM, rmsnorm_quant_f16(h, resid, nullptr, (const half_t *)w.attn_norm_gamma, c.rms_eps, T, H, false, xqn, xsn, st));
-            TIMED(LLMIE_OP_QKV_GEMM, (gemm256_launch(true, xqn, w.qkv.data, qkv, T, QKV, H, nullptr, nullptr, xsn, (const float *)w.qkv.scale, st),
-                                      launch_status("decoder_prefill(qkv fp8)")));
+            if (rope_fusable && reinterpret_cast<uintptr_t>(w.qkv.bias) % 8 == 0 &&
+                gemm256_qkv_rope_eligible(1, T, QKV, H, xqn, w.qkv.data, w.qkv.scale, qkv)) {
+                fused = 1;
+                TIMED(LLMIE_OP_QKV_GEMM, qkv_rope(l, w.qkv, 1, xqn, xsn, w.qkv.data, w.qkv.scale));
+            } else {
+                TIMED(LLMIE_OP_QKV_GEMM, (gemm256_launch(true, xqn, w.qkv.data, qkv, T, QKV, H, nullptr, nullptr, xsn, (const float *)w.qkv.scale, st),
+                                          launch_status("decoder_prefill(qkv fp8)")));
+            }
         } else {
-        TIMED(LLMIE_OP_ATTN_NORM, llmie_rmsnorm(h, resid, w.attn_norm_gamma, c.rms_eps, T, H, LLMIE_F16, stream));
-        TIMED(LLMIE_OP_QKV_GEMM, proj(h, w.qkv, qkv, H, QKV, nullptr));
+            TIMED(LLMIE_OP_ATTN_NORM, llmie_rmsnorm(h, resid, w.attn_norm_gamma, c.rms_eps, T, H, LLMIE_F16, stream));
+            TIMED(LLMIE_OP_QKV_GEMM, qkv_proj(l, w.qkv, h, &fused));
         }
-        TIMED(LLMIE_OP_MHA, prefill_attention_f16(qkv, (const half_t *)w.qkv.bias, k_cache, v_cache, attn, cum,
-                                                  history_lengths, dec->rope_table, l, batch, T, max_q_len, c.head_num,
-                                                  c.kv_head_num, c.head_size, c.max_seq_len, c.rotary_dim, st,
-                                                  c.kv_fmt == LLMIE_KV_FP8, c.k_scale > 0.f ? c.k_scale : 1.f,
-                                                  c.v_scale > 0.f ? c.v_scale : 1.f, dec->page_table, dec->max_pages, dec->num_pages));
+        TIMED(LLMIE_OP_MHA, attention(l, w.qkv, fused));
         TIMED(LLMIE_OP_O_GEMM, proj(attn, w.o, h, H, H, nullptr));
         const bool gu_fused8 = fp8 && gemm256_swiglu_fills(T, 2 * I) && H % 128 == 0 && reinterpret_cast<uintptr_t>(w.gate_up.data) % 16 == 0;
         if (nq && gu_fused8 && w.ffn_norm_gamma && reinterpret_cast<uintptr_t>(w.gate_up.scale) % 16 == 0) {

@@ -124,6 +124,112 @@ __device__ __forceinline__ void g256_store(floatx4 (&acc)[8][WN], half_t *C, int
     }
 }
 
+// ---- QKV projection with RoPE + KV-cache append in the epilogue (round 3; context_attention.cpp:158-205: the QKV GEMM,
+// launchFusedQKVAddBiasAndTransposeAndRope and launchConcatKVCache of the prefill as ONE launch) ----
+// The eight-phase kernels (gemm8p.cuh, ROPE = true) give every wave the 64 (256-wide tile) or 32 (128-wide tile) output columns
+// {d, d + 64} x 32 / 16 of ONE head -- the weight rows of a tile are fetched in a permuted order, qkv_rope_col() -- so both halves
+// of every rotate-half pair sit in the accumulators of one lane: acc[i][j] and acc[i][j + WN / 2].  The epilogue then does what
+// prefill_rope_append_kernel (prefill.hip) does to the fp16 QKV row, on the fp16-ROUNDED accumulator (bit-identical results):
+// + bias, rotate q and k heads by the token's (cos, sin) row, store q into the packed QKV buffer, k and v straight into the cache
+// slot history + position (dense slab or 128-token pages; fp16 or e4m3).  K / V never travel through the QKV buffer.
+// (struct QkvRopeArgs: device_utils.cuh)
+// tile column c (0 .. 64 WN - 1, in units of the workgroup tile) -> column inside its 128-wide head
+template <int WN> __device__ __forceinline__ int qkv_rope_col(int c) {
+    if constexpr (WN == 4) return (c & ~0x7f) | ((c & 0x20) << 1) | ((c & 0x40) >> 1) | (c & 0x1f);   // 256-wide: swap bits 5 and 6
+    else return ((c & 0x10) << 2) | ((c & 0x60) >> 1) | (c & 0xf);                                     // 128-wide: [wc:2][jj][4] -> [jj][wc:2][4]
+}
+// acc[i][j]: lane (r, q) holds row m0 + wr*128 + i*16 + r, PERMUTED tile column wcol + j*16 + 4q + e; n0 = first column of the
+// tile in the whole [T, (nh + 2 kvh) * 128] output (a multiple of 128)
+template <bool FP8, int WN, int WQ>
+__device__ __forceinline__ void g256_store_qkv_rope(floatx4 (&acc)[8][WN], half_t *qkv, int M, size_t ldc, int m0, int n0, int wr, int wcol,
+                                                    int r, int q, const float *__restrict__ xscale, const float *__restrict__ wscale,
+                                                    const half_t *__restrict__ bias, const QkvRopeArgs *__restrict__ rap, int layer) {
+    const QkvRopeArgs ra = *rap;   // (wave-uniform address: scalar loads, issued here -- behind the main loop)
+    // the lane's (r, q) re-derived from the lane id the hardware counts (mbcnt) instead of the values the main loop was built on:
+    // nothing of this epilogue's address arithmetic can be computed in front of the loop and kept in registers across it (the
+    // e4m3 256 x 256 form sits at 256 VGPRs and spilled two such values around its loop)
+    {
+        const int lane_now = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        r = lane_now & 15;
+        q = lane_now >> 4;
+    }
+    const size_t layer_off = static_cast<size_t>(layer) * ra.layer_stride;
+    constexpr int HS = 128, HP = WN / 2;   // pairs (j, j + HP)
+    const half_t *hscale = reinterpret_cast<const half_t *>(wscale);
+    (void)hscale;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + r;
+        if (m >= M) continue;
+        const int tpos = ra.tok_tpos[m], b = ra.tok_b[m];
+        if (tpos < 0 || tpos >= ra.max_seq_len) continue;   // (prefill_rope_append_kernel: never write outside the slab)
+        const float xsm = FP8 ? xscale[m] : 1.f;
+#pragma unroll
+        for (int j = 0; j < HP; ++j) {
+            const int c = wcol + j * 16 + 4 * q;             // permuted tile column of e = 0 (first half of the pair)
+            const int cn = n0 + qkv_rope_col<WN>(c);         // its output column: head * 128 + d, d < 64
+            const int head = cn >> 7, d = cn & 127;
+            floatx4 lo = acc[i][j], hi = acc[i][j + HP];
+            if constexpr (FP8) {
+                const floatx4 wl = *reinterpret_cast<const floatx4 *>(wscale + cn), wh = *reinterpret_cast<const floatx4 *>(wscale + cn + 64);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo[e] *= wl[e] * xsm;
+                    hi[e] *= wh[e] * xsm;
+                }
+            }
+            if constexpr (WQ != 0) {
+                const half4_t wl = *reinterpret_cast<const half4_t *>(hscale + cn), wh = *reinterpret_cast<const half4_t *>(hscale + cn + 64);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo[e] *= to_f32(wl[e]);
+                    hi[e] *= to_f32(wh[e]);
+                }
+            }
+            half4_t blo{0, 0, 0, 0}, bhi{0, 0, 0, 0};
+            if (bias) {
+                blo = *reinterpret_cast<const half4_t *>(bias + cn);
+                bhi = *reinterpret_cast<const half4_t *>(bias + cn + 64);
+            }
+            const bool rotate = head < ra.head_num + ra.kv_head_num;
+            half4_t olo, ohi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // the projection's output as the unfused sequence stores it (fp16), then prefill_rope_append_kernel's arithmetic
+                const float x0 = to_f32(from_f32<half_t>(lo[e])) + to_f32(blo[e]), x1 = to_f32(from_f32<half_t>(hi[e])) + to_f32(bhi[e]);
+                float o0 = x0, o1 = x1;
+                if (rotate && d + e < (ra.rotary_dim >> 1)) {
+                    const float2 v = ra.rope[static_cast<size_t>(tpos) * (HS / 2) + d + e];
+                    o0 = x0 * v.x - x1 * v.y;
+                    o1 = x1 * v.x + x0 * v.y;
+                }
+                olo[e] = from_f32<half_t>(o0);
+                ohi[e] = from_f32<half_t>(o1);
+            }
+            if (head < ra.head_num) {
+                half_t *dst = qkv + static_cast<size_t>(m) * ldc + cn;
+                *reinterpret_cast<half4_t *>(dst) = olo;
+                *reinterpret_cast<half4_t *>(dst + 64) = ohi;
+            } else {
+                const bool is_k = head < ra.head_num + ra.kv_head_num;
+                const int g = is_k ? head - ra.head_num : head - ra.head_num - ra.kv_head_num;
+                const size_t off = ra.table ? layer_off + ((static_cast<size_t>(ra.table[static_cast<size_t>(b) * ra.max_pages + tpos / 128]) * ra.kv_head_num + g) * 128 + tpos % 128) * HS
+                                            : layer_off + ((static_cast<size_t>(b) * ra.kv_head_num + g) * ra.max_seq_len + tpos) * HS;
+                if (ra.kv8) {
+                    uint8_t *dst = static_cast<uint8_t *>(is_k ? ra.k_cache : ra.v_cache) + off + d;
+                    const float inv = is_k ? ra.k_inv_scale : ra.v_inv_scale;
+                    *reinterpret_cast<unsigned *>(dst) = pack4_e4m3(to_f32(olo[0]) * inv, to_f32(olo[1]) * inv, to_f32(olo[2]) * inv, to_f32(olo[3]) * inv);
+                    *reinterpret_cast<unsigned *>(dst + 64) = pack4_e4m3(to_f32(ohi[0]) * inv, to_f32(ohi[1]) * inv, to_f32(ohi[2]) * inv, to_f32(ohi[3]) * inv);
+                } else {
+                    half_t *dst = static_cast<half_t *>(is_k ? ra.k_cache : ra.v_cache) + off + d;
+                    *reinterpret_cast<half4_t *>(dst) = olo;
+                    *reinterpret_cast<half4_t *>(dst + 64) = ohi;
+                }
+            }
+        }
+    }
+}
+
 // WN = MFMA column tiles per wave: 4 -> 256 x 256 workgroup tile, 2 -> 256 x 128 (one W half per stage, 96 KiB of LDS) for
 // projections whose 256-wide grid would leave CUs idle (N = 4096 at 2048 tokens: 128 vs 256 workgroups).
 // SWIGLU (WN = 4, W = fused gate_up [2I, K]): the workgroup's 256 weight rows are 128 gate rows n0 .. and the 128 up rows

@@ -112,11 +112,18 @@ __device__ __forceinline__ void g8_wait_groups(int groups) {
 // WQ = 8: W is int8 [N, K] (row pitch K bytes) and wscale points at the fp16 per-row scales; X stays fp16 (FP8 must be false).
 // DMA groups of the weight pieces are then ONE wave instruction per wave (8 KiB) instead of two, so the counted waits differ per
 // phase: behind phase (u, s) the groups 4u+s+3 .. 4u+s+7 stay in flight = A B A B A (8 instructions) for even s, B A B A B (7) for odd.
-template <bool FP8, bool HAS_EPI, bool SWIGLU = false, int WQ = 0>
+// ROPE (round 3): the QKV projection of a prefill with RoPE + KV-cache append as its epilogue (g256_store_qkv_rope, gemm256.cuh):
+// the weight rows of a tile are fetched in the permuted order qkv_rope_col() so that a lane holds both halves of every rotate-half
+// pair; col0 = first output column of this launch's range (a multiple of 128), C = the packed QKV buffer (un-offset), ldc its row
+// pitch; K / V columns go to the caches only.  `rap` points at the DEVICE-resident, layer-invariant operands of the epilogue (read
+// after the main loop: as by-value kernel arguments they sat in ~25 SGPRs through the loop and the int8 forms spilled scalars,
+// which the hand-issued DMA cannot tolerate), `bias` = this layer's QKV bias or null, `layer` selects the cache slab.
+template <bool FP8, bool HAS_EPI, bool SWIGLU = false, int WQ = 0, bool ROPE = false>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const void *__restrict__ Xv, const void *__restrict__ Wv, half_t *C, int M, int N,
                                                      int K, const half_t *__restrict__ bias, const half_t *residual, int tiles_n,
                                                      const float *__restrict__ xscale, const float *__restrict__ wscale,
-                                                     int ldc_arg = 0, int group_m = 0, int col0 = 0) {
+                                                     int ldc_arg = 0, int group_m = 0, int col0 = 0, const QkvRopeArgs *__restrict__ rap = nullptr, int layer = 0) {
+    static_assert(!ROPE || (!HAS_EPI && !SWIGLU), "ROPE form: the plain projection");
     // col0 (SwiGLU form): first output column of this launch's range (a launch over columns [col0, col0 + tiles_n * 128) of C[M, I])
     static_assert(!SWIGLU || !HAS_EPI, "SwiGLU form: no bias / residual");
     static_assert(WQ == 0 || (WQ == 8 && !FP8), "WQ: 0 (operands as they are) or 8 (int8 weights under fp16 activations)");
@@ -179,6 +186,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void *__restrict__ Xv
                     const int row = row0 + (lane >> 2), chunk = static_cast<int>(g8_q8_slot(row, lane & 3));
                     long grow;
                     if (SWIGLU) grow = static_cast<long>(half - 2) * half_n + min(n0 + row, half_n - 1) - n0;
+                    else if (ROPE) grow = qkv_rope_col<4>((half - 2) * 128 + row);
                     else grow = min(n0 + (half - 2) * 128 + row, N - 1) - n0;
                     voff[kind][i] = static_cast<unsigned>(grow * static_cast<long>(wrow_bytes) + chunk * 16);
                     ldst[kind][i] = __builtin_amdgcn_readfirstlane(lds_addr + half * HALF_BYTES + row0 * 64);
@@ -201,6 +209,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void *__restrict__ Xv
             long grow;   // row relative to the tile base, clamped to the matrix (edge rows are never stored)
             if (half < 2) grow = min(m0 + half * 128 + row, M - 1) - m0;
             else if (SWIGLU) grow = static_cast<long>(half - 2) * half_n + min(n0 + row, half_n - 1) - n0;
+            else if (ROPE) grow = qkv_rope_col<4>((half - 2) * 128 + row);
             else grow = min(n0 + (half - 2) * 128 + row, N - 1) - n0;
             voff[kind][i] = static_cast<unsigned>(grow * static_cast<long>(row_bytes) + chunk * 16);
             ldst[kind][i] = __builtin_amdgcn_readfirstlane(lds_addr + half * HALF_BYTES + row0 * 128);
@@ -348,6 +357,10 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void *__restrict__ Xv
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with the second row's last barrier
 
+    if constexpr (ROPE) {   // (C, xscale, wscale and the bias are whole-matrix pointers: the epilogue indexes them by absolute column)
+        g256_store_qkv_rope<FP8, 4, WQ>(acc, C, M, ldc, m0, col0 + n0, wr, wcol, r, q, xscale, wscale, bias, rap, layer);
+        return;
+    }
     g256_store<FP8, HAS_EPI, 4, SWIGLU, WQ>(acc, C, M, N, ldc, m0, n0, wr, wcol, r, q, bias, residual, xscale, wscale);
 }
 
@@ -374,11 +387,12 @@ __device__ __forceinline__ void g8_wait_instrs(int n) {   // n = DMA wave instru
 // WQ = 8 (int8 weights, as in gemm8p_kernel): the B group is one wave instruction per wave (128 rows x 64 B in the first half of its
 // slot); behind phase 2u the groups 3u+4 .. 3u+7 = A0 A1 B A0 stay in flight (7 instructions), behind phase 2u + 1 the groups
 // 3u+5 .. 3u+9 = A1 B A0 A1 B (8).
-template <bool FP8, bool HAS_EPI, bool SWIGLU = false, int WQ = 0>
+template <bool FP8, bool HAS_EPI, bool SWIGLU = false, int WQ = 0, bool ROPE = false>
 __global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict__ Xv, const void *__restrict__ Wv, half_t *C, int M, int N,
                                                           int K, const half_t *__restrict__ bias, const half_t *residual, int tiles_n,
                                                           const float *__restrict__ xscale, const float *__restrict__ wscale,
-                                                          int ldc_arg = 0, int group_m = 0, int col0 = 0) {
+                                                          int ldc_arg = 0, int group_m = 0, int col0 = 0, const QkvRopeArgs *__restrict__ rap = nullptr, int layer = 0) {
+    static_assert(!ROPE || (!HAS_EPI && !SWIGLU), "ROPE form: the plain projection");
     static_assert(!SWIGLU || !HAS_EPI, "SwiGLU form: no bias / residual");
     static_assert(WQ == 0 || (WQ == 8 && !FP8), "WQ: 0 (operands as they are) or 8 (int8 weights under fp16 activations)");
     const int half_n = N >> 1;
@@ -422,6 +436,7 @@ __global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict
         ldst_b = __builtin_amdgcn_readfirstlane(lds_addr + wave * 1024);
         long grow;
         if constexpr (SWIGLU) grow = static_cast<long>(row >> 6) * half_n + min(n0 + (row & 63), half_n - 1) - n0;
+        else if constexpr (ROPE) grow = qkv_rope_col<2>(row);
         else grow = min(n0 + row, N - 1) - n0;
         voff[0][0] = static_cast<unsigned>(grow * static_cast<long>(wrow_bytes) + chunk * 16);
         voff[0][1] = 0;
@@ -433,6 +448,8 @@ __global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict
         if constexpr (WQ != 0) {
         } else if constexpr (SWIGLU)   // slot rows 0-63: gate rows n0 + row; 64-127: up rows I + n0 + row - 64 (clamped inside their half)
             voff[0][i] = static_cast<unsigned>((static_cast<long>(row >> 6) * half_n + min(n0 + (row & 63), half_n - 1) - n0) * static_cast<long>(row_bytes) + chunk * 16);
+        else if constexpr (ROPE)
+            voff[0][i] = static_cast<unsigned>(static_cast<long>(qkv_rope_col<2>(row)) * static_cast<long>(row_bytes) + chunk * 16);
         else
             voff[0][i] = static_cast<unsigned>(static_cast<long>(min(n0 + row, N - 1) - n0) * static_cast<long>(row_bytes) + chunk * 16);
 #pragma unroll
@@ -568,6 +585,10 @@ __global__ __launch_bounds__(512) void gemm8p_n128_kernel(const void *__restrict
     if (u + 1 < KT) { phase(std::integral_constant<int, 2>{}, u + 1, std::false_type{}); phase(std::integral_constant<int, 3>{}, u + 1, std::false_type{}); }
     if (wr == 0) __builtin_amdgcn_s_barrier();
 
+    if constexpr (ROPE) {
+        g256_store_qkv_rope<FP8, 2, WQ>(acc, C, M, ldc, m0, col0 + n0, wr, wcol, r, q, xscale, wscale, bias, rap, layer);
+        return;
+    }
     g256_store<FP8, HAS_EPI, 2, SWIGLU, WQ>(acc, C, M, N, ldc, m0, n0, wr, wcol, r, q, bias, residual, xscale, wscale);
 }
 

@@ -768,6 +768,86 @@ void gemm256_launch(bool fp8, const void *x, const void *W, half_t *y, int M, in
     }
 }
 
+// ---- QKV projection of a prefill with RoPE + KV-cache append as its epilogue (gemm8p.cuh ROPE forms; context_attention.cpp:158-205
+// as one launch sequence).  kind: 0 = fp16 operands, 1 = e4m3 operands (xscale / wscale), 8 = int8 weights (wscale = fp16 row scales).
+// N = (head_num + 2 kv_head_num) * 128; the tile plan is gemm256_launch's, with every column range a whole number of tiles (a tile
+// never straddles the end of the matrix: the ROPE forms fetch their weight rows unclamped, in permuted order).
+bool gemm256_qkv_rope_eligible(int kind, int M, int N, int K, const void *x, const void *W, const void *wscale, const void *qkv) {
+    const bool fp8 = kind == 1;
+    return N % 128 == 0 && K % (fp8 ? 128 : 64) == 0 && gemm256_fills(M, N) &&
+           (static_cast<size_t>(N) + 512) * K * (fp8 ? 1 : 2) < (size_t{1} << 32) &&
+           (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) % 16 == 0 &&
+           (reinterpret_cast<uintptr_t>(wscale) % (fp8 ? 16 : 8)) == 0 && reinterpret_cast<uintptr_t>(qkv) % 8 == 0;
+}
+template <bool FP8, int WQ, int WN>
+static void qkv_rope_range(const void *x, const void *W, half_t *qkv, int M, int N, int K, const float *xscale, const float *wscale,
+                           const half_t *bias, const QkvRopeArgs *rap, int layer, hipStream_t st, int nb, int n) {
+    // W is offset to the range like every range launch; C, the scales and the bias stay whole: the epilogue indexes them by the
+    // absolute output column col0 + tile column.  rap: DEVICE pointer (prefill_token_table); bias: this layer's QKV bias or null
+    const void *Wr = static_cast<const unsigned char *>(W) + static_cast<size_t>(nb) * K * ((FP8 || WQ) ? 1 : 2);
+    const int tm = (M + 255) / 256, tn = n / (64 * WN);
+    if constexpr (WN == 4) {
+        constexpr int lds_bytes = 2 * 4 * 128 * 128;
+        static const bool attr = [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm8p_kernel<FP8, false, false, WQ, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            return true;
+        }();
+        (void)attr;
+        gemm8p_kernel<FP8, false, false, WQ, true><<<tm * tn, 512, lds_bytes, st>>>(x, Wr, qkv, M, n, K, bias, nullptr, tn, xscale, wscale, N,
+                                                                                   g256_group_m(), nb, rap, layer);
+    } else {
+        constexpr int ring_bytes = 9 * 128 * 128;
+        static const bool attr = [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm8p_n128_kernel<FP8, false, false, WQ, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, ring_bytes);
+            return true;
+        }();
+        (void)attr;
+        gemm8p_n128_kernel<FP8, false, false, WQ, true><<<tm * tn, 512, ring_bytes, st>>>(x, Wr, qkv, M, n, K, bias, nullptr, tn, xscale, wscale, N,
+                                                                                         g256_group_m(), nb, rap, layer);
+    }
+}
+void gemm256_qkv_rope_launch(int kind, const void *x, const void *W, half_t *qkv, int M, int N, int K, const float *xscale,
+                             const float *wscale, const half_t *bias, const QkvRopeArgs *rap, int layer, hipStream_t st) {
+    constexpr int cus = 256;
+    const int tm = (M + 255) / 256, tn4 = N / 256, tn2 = N / 128;
+    auto rounds = [&](int t) { return (t + cus - 1) / cus; };
+    const float narrow = 0.6f;
+    // candidates: all 128-wide; all 256-wide (N a multiple of 256); whole rounds 256-wide + the rest 128-wide
+    int plan = 2, a_tn = 0;
+    float best = rounds(tm * tn2) * narrow;
+    if (gemm256_wn(M, N) != 2) {
+        if (N % 256 == 0 && static_cast<float>(rounds(tm * tn4)) < best) {
+            best = static_cast<float>(rounds(tm * tn4));
+            plan = 4;
+        }
+        const int a = (tm * tn4 / cus) * cus / tm;   // 256-wide column tiles that make whole rounds
+        if (a > 0 && a * 256 < N) {
+            const float c = static_cast<float>(rounds(tm * a)) + rounds(tm * ((N - a * 256) / 128)) * narrow;
+            if (c < best) {
+                best = c;
+                plan = 42;
+                a_tn = a;
+            }
+        }
+    }
+    auto range = [&](int wn, int nb, int n) {
+#define LLMIE_QR(F8_, WQ_) (wn == 4 ? qkv_rope_range<F8_, WQ_, 4>(x, W, qkv, M, N, K, xscale, wscale, bias, rap, layer, st, nb, n) \
+                                    : qkv_rope_range<F8_, WQ_, 2>(x, W, qkv, M, N, K, xscale, wscale, bias, rap, layer, st, nb, n))
+        if (kind == 1) LLMIE_QR(true, 0);
+        else if (kind == 8) LLMIE_QR(false, 8);
+        else LLMIE_QR(false, 0);
+#undef LLMIE_QR
+    };
+    if (plan == 42) {
+        range(4, 0, a_tn * 256);
+        range(2, a_tn * 256, N - a_tn * 256);
+    } else {
+        range(plan, 0, N);
+    }
+}
+
 // int8 [N, K] weights through the eight-phase kernels (gemm8p.cuh, WQ = 8): prefill-sized M whose 256-row grid fills the chip
 bool g8p_w8_eligible(int M, int K, int N, const void *x, const void *wq, const void *scale, const void *y) {
     return K % 64 == 0 && N % 4 == 0 && gemm256_fills(M, N) && (static_cast<size_t>(N) + 512) * K * 2 < (size_t{1} << 32) &&

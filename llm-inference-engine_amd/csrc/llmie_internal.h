@@ -59,6 +59,12 @@ bool gemm256_swiglu_fills(int M, int two_inter);
 void gemm256_swiglu_launch(bool fp8, const void *x, const void *W, half_t *y, int M, int two_inter, int K, const float *xscale,
                            const float *wscale, hipStream_t st, int wq = 0);
 bool g8p_w8_eligible(int M, int K, int N, const void *x, const void *wq, const void *scale, const void *y);
+// QKV projection with RoPE + KV-cache append as its epilogue (gemm8p.cuh ROPE forms): kind 0 = fp16, 1 = e4m3 operands, 8 = int8
+// weights (wscale = fp16 row scales); q columns -> qkv (rotated), k / v columns -> the caches only; linear.hip
+bool gemm256_qkv_rope_eligible(int kind, int M, int N, int K, const void *x, const void *W, const void *wscale, const void *qkv);
+// rap: the epilogue's layer-invariant operands in DEVICE memory (prefill_token_table writes them); bias: the layer's QKV bias or null
+void gemm256_qkv_rope_launch(int kind, const void *x, const void *W, half_t *qkv, int M, int N, int K, const float *xscale,
+                             const float *wscale, const half_t *bias, const QkvRopeArgs *rap, int layer, hipStream_t st);
 bool g8p_w8_swiglu_eligible(int M, int K, int two_inter, const void *x, const void *wq, const void *scale, const void *y);
 // fp16 image of int8 / int4 weights (row scales / group scales applied, one rounding): the operand of the prefill-sized
 // projections that have no in-kernel de-quantising form; quant_linear.hip
@@ -145,6 +151,11 @@ int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, void *k_cache, vo
                           int num_tokens, int max_q_len, int head_num, int kv_head_num, int head_size, int max_seq_len,
                           int rotary_dim, hipStream_t st, int kv_fp8 = 0 /* caches are e4m3 bytes */, float k_scale = 1.f,
                           float v_scale = 1.f, const int32_t *block_table = nullptr /* paged cache, see decoder_mha_rope */,
-                          int max_pages = 0, int num_pages = 0);
+                          int max_pages = 0, int num_pages = 0,
+                          int rope_done = 0 /* RoPE + append already done by the QKV projection's epilogue (gemm256_qkv_rope_launch) */);
+// tok_b[t] / tok_tpos[t] = sequence / cache position (history + position) of packed token t: operands of that epilogue
+// (also copies `args` -- whose tok_b / tok_tpos it fills in -- to args_dev)
+int prefill_token_table(const int32_t *cum_seqlens, const int32_t *history_len, int batch, int num_tokens, int32_t *tok_b, int32_t *tok_tpos,
+                        QkvRopeArgs args, QkvRopeArgs *args_dev, hipStream_t st);
 
 }  // namespace llmie

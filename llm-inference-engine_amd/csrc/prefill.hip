@@ -103,6 +103,27 @@ __global__ __launch_bounds__(256) void prefill_rope_append_kernel(half_t *__rest
     }
 }
 
+// Per-token (sequence, cache position) table for the QKV projection's fused RoPE + append epilogue (gemm256.cuh
+// g256_store_qkv_rope): tok_b[t] = sequence of packed token t, tok_tpos[t] = history + position.  Once per prefill call.
+__global__ __launch_bounds__(256) void prefill_token_table_kernel(const int32_t *__restrict__ cum, const int32_t *__restrict__ hist, int batch,
+                                                                  int num_tokens, int32_t *__restrict__ tok_b, int32_t *__restrict__ tok_tpos,
+                                                                  const QkvRopeArgs args, QkvRopeArgs *__restrict__ args_dev) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t == 0) *args_dev = args;
+    if (t >= num_tokens) return;
+    int b, pos;
+    locate_token(cum, batch, t, b, pos);
+    tok_b[t] = b;
+    tok_tpos[t] = hist[b] + pos;
+}
+int prefill_token_table(const int32_t *cum_seqlens, const int32_t *history_len, int batch, int num_tokens, int32_t *tok_b, int32_t *tok_tpos,
+                        QkvRopeArgs args, QkvRopeArgs *args_dev, hipStream_t st) {
+    args.tok_b = tok_b;
+    args.tok_tpos = tok_tpos;
+    prefill_token_table_kernel<<<(num_tokens + 255) / 256, 256, 0, st>>>(cum_seqlens, history_len, batch, num_tokens, tok_b, tok_tpos, args, args_dev);
+    return launch_status("prefill_token_table");
+}
+
 // grid: (q tiles of NW*16 rows over max_q_len, head_num, batch); block = NW waves x 16 query rows.  NW = 8: a staged 64-key K/V
 // tile (global -> LDS, two barriers: 80 of the 175 us of the 4-wave form at 2048 tokens) serves 128 query rows.
 template <int HS, bool KV8, int NW>
@@ -341,7 +362,7 @@ int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, void *k_cache, vo
                           const int32_t *cum_seqlens, const int32_t *history_len, const float2 *rope, int layer, int batch,
                           int num_tokens, int max_q_len, int head_num, int kv_head_num, int head_size, int max_seq_len,
                           int rotary_dim, hipStream_t st, int kv_fp8, float k_scale, float v_scale, const int32_t *block_table,
-                          int max_pages, int num_pages) {
+                          int max_pages, int num_pages, int rope_done) {
     if (head_size != 128) {
         set_error("prefill attention: head_size %d not supported by the flash kernel (128 only)", head_size);
         return LLMIE_ERR_UNSUPPORTED;
@@ -352,7 +373,8 @@ int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, void *k_cache, vo
     const int bq = nw * 16;
     dim3 grid((max_q_len + bq - 1) / bq, head_num, batch);
     const float ks = kv_fp8 ? k_scale : 1.f, vs = kv_fp8 ? v_scale : 1.f;
-    if (kv_fp8)
+    if (rope_done) {   // the QKV projection's epilogue rotated q in `qkv` and wrote k / v into the caches
+    } else if (kv_fp8)
         prefill_rope_append_kernel<128, true><<<num_tokens, 256, 0, st>>>(qkv, qkv_bias, k_cache, v_cache, cum_seqlens, history_len,
                                                                           rope, batch, head_num, kv_head_num, max_seq_len,
                                                                           rotary_dim, layer_off, 1.0f / ks, 1.0f / vs, block_table, max_pages);
