@@ -153,78 +153,129 @@ __device__ __forceinline__ void g256_store_qkv_rope(floatx4 (&acc)[8][WN], half_
         r = lane_now & 15;
         q = lane_now >> 4;
     }
+    // pointers that came out of the struct are global memory (the compiler would issue flat accesses, which also count on lgkmcnt)
+    typedef __attribute__((address_space(1))) const int32_t *gi32_t;
+    typedef __attribute__((address_space(1))) const floatx4 *gf4_t;
+    const gi32_t tok_tpos = (gi32_t)ra.tok_tpos, tok_b = (gi32_t)ra.tok_b, table = (gi32_t)ra.table;
     const size_t layer_off = static_cast<size_t>(layer) * ra.layer_stride;
     constexpr int HS = 128, HP = WN / 2;   // pairs (j, j + HP)
     const half_t *hscale = reinterpret_cast<const half_t *>(wscale);
     (void)hscale;
+    // the head a wave's columns belong to is wave-uniform: (n0 + permuted wcol) / 128 for every j (the 16 j + 4 q + e part stays below 64)
+    const int head = __builtin_amdgcn_readfirstlane((n0 + qkv_rope_col<WN>(wcol)) >> 7);
+    const bool is_q = head < ra.head_num, is_k = !is_q && head < ra.head_num + ra.kv_head_num, rotate = is_q || is_k;
+    const int g = is_k ? head - ra.head_num : head - ra.head_num - ra.kv_head_num;
+    const int half_rot = rotate ? (ra.rotary_dim >> 1) : 0;
+    // this lane's 8 rows: cache position and sequence, all loads in flight at once
+    int tposv[8], bv[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wr * 128 + i * 16 + r;
-        if (m >= M) continue;
-        const int tpos = ra.tok_tpos[m], b = ra.tok_b[m];
-        if (tpos < 0 || tpos >= ra.max_seq_len) continue;   // (prefill_rope_append_kernel: never write outside the slab)
-        const float xsm = FP8 ? xscale[m] : 1.f;
+        const int m = min(m0 + wr * 128 + i * 16 + r, M - 1);
+        tposv[i] = tok_tpos[m];
+        bv[i] = is_q ? 0 : tok_b[m];
+    }
+    // per column pair j: column-in-head d, scales and bias (the same for every row)
+    int dj[HP];
+    half4_t blo[HP], bhi[HP];
+    floatx4 sl[HP], sh[HP];
+#pragma unroll
+    for (int j = 0; j < HP; ++j) {
+        const int cn = n0 + qkv_rope_col<WN>(wcol + j * 16 + 4 * q);   // output column of e = 0, first half of the pair: head * 128 + d, d < 64
+        dj[j] = cn & 127;
+        blo[j] = half4_t{0, 0, 0, 0};
+        bhi[j] = blo[j];
+        if (bias) {
+            blo[j] = *reinterpret_cast<const half4_t *>(bias + cn);
+            bhi[j] = *reinterpret_cast<const half4_t *>(bias + cn + 64);
+        }
+        if constexpr (FP8) {
+            sl[j] = *reinterpret_cast<const floatx4 *>(wscale + cn);
+            sh[j] = *reinterpret_cast<const floatx4 *>(wscale + cn + 64);
+        }
+        if constexpr (WQ != 0) {
+            const half4_t wl = *reinterpret_cast<const half4_t *>(hscale + cn), wh = *reinterpret_cast<const half4_t *>(hscale + cn + 64);
+            sl[j] = floatx4{to_f32(wl[0]), to_f32(wl[1]), to_f32(wl[2]), to_f32(wl[3])};
+            sh[j] = floatx4{to_f32(wh[0]), to_f32(wh[1]), to_f32(wh[2]), to_f32(wh[3])};
+        }
+    }
+    // (cos, sin) of the lane's 4 HP rotation pairs of a row: two 16-byte loads per j.  Row i + 1's are requested before row i is
+    // rotated and stored (straight-line code: a row that must not be written -- past M, or a cache position outside the slab -- loads
+    // from a clamped position and skips its stores), so the L2 round trip of one row hides under the arithmetic of another; v heads
+    // load nothing
+    floatx4 cs[2][HP][2];
+    auto load_cs = [&](int i, floatx4 (&c)[HP][2]) {
+        const int tp = min(max(tposv[i], 0), ra.max_seq_len - 1);
 #pragma unroll
         for (int j = 0; j < HP; ++j) {
-            const int c = wcol + j * 16 + 4 * q;             // permuted tile column of e = 0 (first half of the pair)
-            const int cn = n0 + qkv_rope_col<WN>(c);         // its output column: head * 128 + d, d < 64
-            const int head = cn >> 7, d = cn & 127;
+            const gf4_t rp = (gf4_t)(ra.rope + static_cast<size_t>(tp) * (HS / 2) + dj[j]);
+            c[j][0] = rp[0];   // cos(d), sin(d), cos(d + 1), sin(d + 1)
+            c[j][1] = rp[1];
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < HP; ++j) cs[0][j][0] = cs[0][j][1] = cs[1][j][0] = cs[1][j][1] = floatx4{1.f, 0.f, 1.f, 0.f};
+    if (rotate) load_cs(0, cs[0]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + r, tpos = tposv[i];
+        const bool valid = m < M && tpos >= 0 && tpos < ra.max_seq_len;   // (prefill_rope_append_kernel: never write outside the slab)
+        if (rotate && i + 1 < 8) load_cs(i + 1, cs[(i + 1) & 1]);
+        const float xsm = FP8 ? xscale[min(m, M - 1)] : 1.f;
+        const int tpc = min(max(tpos, 0), ra.max_seq_len - 1);
+        size_t row_off = 0;   // element offset of this token's row in its kv head's cache slab
+        if (!is_q)
+            row_off = table ? layer_off + ((static_cast<size_t>(table[static_cast<size_t>(bv[i]) * ra.max_pages + tpc / 128]) * ra.kv_head_num + g) * 128 + tpc % 128) * HS
+                            : layer_off + ((static_cast<size_t>(bv[i]) * ra.kv_head_num + g) * ra.max_seq_len + tpc) * HS;
+#pragma unroll
+        for (int j = 0; j < HP; ++j) {
             floatx4 lo = acc[i][j], hi = acc[i][j + HP];
+            const floatx4 cs0 = cs[i & 1][j][0], cs1 = cs[i & 1][j][1];
+            const int d = dj[j];
             if constexpr (FP8) {
-                const floatx4 wl = *reinterpret_cast<const floatx4 *>(wscale + cn), wh = *reinterpret_cast<const floatx4 *>(wscale + cn + 64);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    lo[e] *= wl[e] * xsm;
-                    hi[e] *= wh[e] * xsm;
+                    lo[e] *= sl[j][e] * xsm;
+                    hi[e] *= sh[j][e] * xsm;
                 }
             }
             if constexpr (WQ != 0) {
-                const half4_t wl = *reinterpret_cast<const half4_t *>(hscale + cn), wh = *reinterpret_cast<const half4_t *>(hscale + cn + 64);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    lo[e] *= to_f32(wl[e]);
-                    hi[e] *= to_f32(wh[e]);
+                    lo[e] *= sl[j][e];
+                    hi[e] *= sh[j][e];
+                    // keep "fp32 product, then one conversion" (what g256_store's packed multiplies + v_cvt_pk_f16_f32 compute): left
+                    // to itself the compiler folds a low-half fp16 scale, the product and the conversion into v_fma_mixlo_f16, which
+                    // rounds the exact product ONCE -- 1 ulp away from the two-launch sequence in ~1e-4 of the elements
+                    asm volatile("" : "+v"(lo[e]), "+v"(hi[e]));
                 }
             }
-            half4_t blo{0, 0, 0, 0}, bhi{0, 0, 0, 0};
-            if (bias) {
-                blo = *reinterpret_cast<const half4_t *>(bias + cn);
-                bhi = *reinterpret_cast<const half4_t *>(bias + cn + 64);
-            }
-            const bool rotate = head < ra.head_num + ra.kv_head_num;
             half4_t olo, ohi;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 // the projection's output as the unfused sequence stores it (fp16), then prefill_rope_append_kernel's arithmetic
-                const float x0 = to_f32(from_f32<half_t>(lo[e])) + to_f32(blo[e]), x1 = to_f32(from_f32<half_t>(hi[e])) + to_f32(bhi[e]);
-                float o0 = x0, o1 = x1;
-                if (rotate && d + e < (ra.rotary_dim >> 1)) {
-                    const float2 v = ra.rope[static_cast<size_t>(tpos) * (HS / 2) + d + e];
-                    o0 = x0 * v.x - x1 * v.y;
-                    o1 = x1 * v.x + x0 * v.y;
-                }
-                olo[e] = from_f32<half_t>(o0);
-                ohi[e] = from_f32<half_t>(o1);
+                const float x0 = to_f32(from_f32<half_t>(lo[e])) + to_f32(blo[j][e]), x1 = to_f32(from_f32<half_t>(hi[e])) + to_f32(bhi[j][e]);
+                const float cv = e < 2 ? cs0[2 * e] : cs1[2 * e - 4], sv = e < 2 ? cs0[2 * e + 1] : cs1[2 * e - 3];
+                const float r0 = x0 * cv - x1 * sv, r1 = x1 * cv + x0 * sv;
+                const bool rot = d + e < half_rot;
+                olo[e] = from_f32<half_t>(rot ? r0 : x0);
+                ohi[e] = from_f32<half_t>(rot ? r1 : x1);
             }
-            if (head < ra.head_num) {
-                half_t *dst = qkv + static_cast<size_t>(m) * ldc + cn;
+            if (!valid) {
+            } else if (is_q) {
+                half_t *dst = qkv + static_cast<size_t>(m) * ldc + (head << 7) + d;
                 *reinterpret_cast<half4_t *>(dst) = olo;
                 *reinterpret_cast<half4_t *>(dst + 64) = ohi;
+            } else if (ra.kv8) {
+                typedef __attribute__((address_space(1))) unsigned *gu32_t;
+                const gu32_t dst = (gu32_t)(static_cast<uint8_t *>(is_k ? ra.k_cache : ra.v_cache) + row_off + d);
+                const float inv = is_k ? ra.k_inv_scale : ra.v_inv_scale;
+                dst[0] = pack4_e4m3(to_f32(olo[0]) * inv, to_f32(olo[1]) * inv, to_f32(olo[2]) * inv, to_f32(olo[3]) * inv);
+                dst[16] = pack4_e4m3(to_f32(ohi[0]) * inv, to_f32(ohi[1]) * inv, to_f32(ohi[2]) * inv, to_f32(ohi[3]) * inv);
             } else {
-                const bool is_k = head < ra.head_num + ra.kv_head_num;
-                const int g = is_k ? head - ra.head_num : head - ra.head_num - ra.kv_head_num;
-                const size_t off = ra.table ? layer_off + ((static_cast<size_t>(ra.table[static_cast<size_t>(b) * ra.max_pages + tpos / 128]) * ra.kv_head_num + g) * 128 + tpos % 128) * HS
-                                            : layer_off + ((static_cast<size_t>(b) * ra.kv_head_num + g) * ra.max_seq_len + tpos) * HS;
-                if (ra.kv8) {
-                    uint8_t *dst = static_cast<uint8_t *>(is_k ? ra.k_cache : ra.v_cache) + off + d;
-                    const float inv = is_k ? ra.k_inv_scale : ra.v_inv_scale;
-                    *reinterpret_cast<unsigned *>(dst) = pack4_e4m3(to_f32(olo[0]) * inv, to_f32(olo[1]) * inv, to_f32(olo[2]) * inv, to_f32(olo[3]) * inv);
-                    *reinterpret_cast<unsigned *>(dst + 64) = pack4_e4m3(to_f32(ohi[0]) * inv, to_f32(ohi[1]) * inv, to_f32(ohi[2]) * inv, to_f32(ohi[3]) * inv);
-                } else {
-                    half_t *dst = static_cast<half_t *>(is_k ? ra.k_cache : ra.v_cache) + off + d;
-                    *reinterpret_cast<half4_t *>(dst) = olo;
-                    *reinterpret_cast<half4_t *>(dst + 64) = ohi;
-                }
+                typedef __attribute__((address_space(1))) half4_t *gh4_t;
+                const gh4_t dst = (gh4_t)(static_cast<half_t *>(is_k ? ra.k_cache : ra.v_cache) + row_off + d);
+                dst[0] = olo;
+                dst[16] = ohi;
             }
         }
     }

@@ -14,6 +14,7 @@ from tests.conftest import load_llmie  # noqa: E402
 llmie = load_llmie()
 DEV, F16 = "cuda", torch.float16
 out_path = sys.argv[1]
+only = sys.argv[2] if len(sys.argv) > 2 else ""   # (debugging aid: one case)
 res = {}
 
 # name, weight format, heads, kv heads, inter, lengths, histories, max_seq, e4m3 cache, paged, qkv bias, rotary_dim
@@ -47,6 +48,8 @@ def quantised(w, wfmt):
 
 
 for name, wfmt, nh, kvh, I, lens, hist, max_seq, kv8, paged, bias, rot in CASES:
+    if only and name != only:
+        continue
     rng = np.random.default_rng(sum(map(ord, name)))
     hs, L = 128, 2
     H, QKV, bs, T = nh * hs, (nh + 2 * kvh) * hs, len(lens), sum(lens)

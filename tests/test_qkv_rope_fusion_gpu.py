@@ -32,4 +32,5 @@ def test_fused_qkv_rope_append_is_bit_identical_to_the_two_launches(tmp_path):
         a, b = fused[k], plain[k]
         if not np.array_equal(a, b):
             bad.append("%s: %d of %d elements differ" % (k, int((a != b).sum()), a.size))
-    assert not bad, bad
+    if bad:
+        pytest.fail("\n".join(bad))
