@@ -1087,12 +1087,16 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
             const bool last = l + 1 == c.num_layers;
             SplitKSlabs sk;
             TIMED(LLMIE_OP_QKV_GEMM, linear_splitk_partial(sbits, h, w.qkv.data, T, H, QKV, st, &sk, slabs, gs_of(w.qkv)));
-            TIMED(LLMIE_OP_QKV_GEMM, splitk_finalize(sk, sc_of(w.qkv), qkv, EPI_NONE_, nullptr, nullptr, st));
-            TIMED(LLMIE_OP_MHA, prefill_attention_f16(qkv, (const half_t *)w.qkv.bias, k_cache, v_cache, attn, cum,
-                                                      history_lengths, dec->rope_table, l, batch, T, max_q_len, c.head_num,
-                                                      c.kv_head_num, c.head_size, c.max_seq_len, c.rotary_dim, st,
-                                                      c.kv_fmt == LLMIE_KV_FP8, c.k_scale > 0.f ? c.k_scale : 1.f,
-                                                      c.v_scale > 0.f ? c.v_scale : 1.f, dec->page_table, dec->max_pages, dec->num_pages));
+            // (the slab consumer of the QKV projection does RoPE + the cache append as well: one launch less per layer)
+            const bool qfuse = !rope_fuse_off && splitk_finalize_qkv_rope_eligible(sk, c.head_size, qkv, w.qkv.bias);
+            if (qfuse) {
+                TIMED(LLMIE_OP_QKV_GEMM, splitk_finalize_qkv_rope(sk, sc_of(w.qkv), qkv, (const half_t *)w.qkv.bias, k_cache, v_cache, cum, history_lengths,
+                                                                  dec->rope_table, l, batch, c.head_num, c.kv_head_num, c.max_seq_len, c.rotary_dim, st,
+                                                                  kv8, ksc, vsc, dec->page_table, dec->max_pages, dec->num_pages));
+            } else {
+                TIMED(LLMIE_OP_QKV_GEMM, splitk_finalize(sk, sc_of(w.qkv), qkv, EPI_NONE_, nullptr, nullptr, st));
+            }
+            TIMED(LLMIE_OP_MHA, attention(l, w.qkv, qfuse ? 1 : 0));
             TIMED(LLMIE_OP_O_GEMM, linear_splitk_partial(sbits, attn, w.o.data, T, H, H, st, &sk, slabs, gs_of(w.o)));
             // context_decoder.cpp: h += resid; resid = h; h += o.bias; h = rmsnorm(h, ffn_gamma)
             TIMED(LLMIE_OP_FFN_NORM, splitk_rownorm(sk, sc_of(w.o), static_cast<const half_t *>(w.o.bias), resid,

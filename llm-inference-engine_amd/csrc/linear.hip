@@ -201,6 +201,79 @@ static __global__ __launch_bounds__(256) void skinny_finalize_kernel(const float
     }
 }
 
+// The same consumer, four columns per thread and every slab load of them in flight at once (round 3).  skinny_finalize_kernel
+// above walks the KS slabs of ONE element with dependent loads -- the slabs were just written by other XCDs, so each is a full
+// memory round trip: 7.4 us per launch at 128 x 12288 x 4 slabs, which is mostly 4 serial latencies.  Same summation order
+// (s0 + s1 + ...), same arithmetic per element: bit-identical results.  N % 4 == 0 (SwiGLU: N % 8 == 0).
+template <bool SWIGLU>
+static __global__ __launch_bounds__(256) void splitk_finalize4_kernel(const float *__restrict__ slab, half_t *y, int M, int N, int KS,
+                                                                      const SlabScale scale, const half_t *__restrict__ bias,
+                                                                      const half_t *residual) {
+    const int out_n = SWIGLU ? N / 2 : N, n4 = out_n / 4;
+    const size_t total = static_cast<size_t>(M) * n4, slab_sz = static_cast<size_t>(M) * N;
+    constexpr int NV = SWIGLU ? 2 : 1;   // column groups per item: the gate columns and the matching up columns
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * 256) {
+        const int m = static_cast<int>(i / n4), n = static_cast<int>(i - static_cast<size_t>(m) * n4) * 4;
+        floatx4 v[NV];
+        for (int k0 = 0; k0 < KS; k0 += 8) {
+            floatx4 t[8][NV];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                for (int g = 0; g < NV; ++g)
+                    t[kk][g] = *reinterpret_cast<const floatx4 *>(slab + static_cast<size_t>(min(k0 + kk, KS - 1)) * slab_sz +
+                                                                  static_cast<size_t>(m) * N + n + g * out_n);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+                if (k0 + kk < KS) {
+#pragma unroll
+                    for (int g = 0; g < NV; ++g) {
+                        if (k0 + kk == 0) v[g] = floatx4{0.f, 0.f, 0.f, 0.f} + t[kk][g];
+                        else v[g] += t[kk][g];
+                    }
+                }
+        }
+        half4_t o4;
+        if constexpr (SWIGLU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gt = scale.apply(v[0][e], m, n + e), up = scale.apply(v[1][e], m, n + e + out_n);
+                o4[e] = from_f32<half_t>((gt / (1.0f + expf(-gt))) * up);
+            }
+        } else {
+            half4_t b4{0, 0, 0, 0}, r4{0, 0, 0, 0};
+            if (bias) b4 = *reinterpret_cast<const half4_t *>(bias + n);
+            if (residual) r4 = *reinterpret_cast<const half4_t *>(residual + static_cast<size_t>(m) * N + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = scale.apply(v[0][e], m, n + e);
+                if (bias) t += to_f32(b4[e]);
+                if (residual) t += to_f32(r4[e]);
+                o4[e] = from_f32<half_t>(t);
+            }
+        }
+        *reinterpret_cast<half4_t *>(y + static_cast<size_t>(m) * out_n + n) = o4;
+    }
+}
+static void launch_finalize(const float *slab, half_t *y, int M, int N, int KS, const SlabScale &sc, const half_t *bias, const half_t *residual,
+                            int epi, hipStream_t st) {
+    const int out_n = epi == EPI_SWIGLU ? N / 2 : N;
+    const bool vec = out_n % 4 == 0 && (reinterpret_cast<uintptr_t>(slab) % 16) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) % 8) == 0;
+    if (vec) {
+        const size_t items = static_cast<size_t>(M) * (out_n / 4);
+        int fgrid = static_cast<int>((items + 255) / 256);
+        if (fgrid > 4096) fgrid = 4096;
+        if (epi == EPI_SWIGLU) splitk_finalize4_kernel<true><<<fgrid, 256, 0, st>>>(slab, y, M, N, KS, sc, bias, residual);
+        else splitk_finalize4_kernel<false><<<fgrid, 256, 0, st>>>(slab, y, M, N, KS, sc, bias, residual);
+        return;
+    }
+    const size_t total = static_cast<size_t>(M) * out_n;
+    int fgrid = static_cast<int>((total + 255) / 256);
+    if (fgrid > 2048) fgrid = 2048;
+    skinny_finalize_kernel<<<fgrid, 256, 0, st>>>(slab, y, M, N, KS, sc, bias, residual, epi);
+}
+
 // Split-K planning, shared by the launcher and by the workspace-size query (the slabs are CALLER-owned: nothing on the
 // compute path allocates, so a first call may already run under hipGraph capture).
 constexpr int kSplitKPassRows = 128;   // activation rows per pass (16 per MFMA tile)
@@ -395,12 +468,8 @@ int linear_splitk(int wbits, const half_t *x, const void *W, const half_t *scale
         SplitKSlabs sk;
         const int rc = linear_splitk_partial(wbits, x + static_cast<size_t>(m0) * K, W, mc, K, N, st, &sk, ws, wbits == 4 ? scale : nullptr);
         if (rc) return rc;
-        const size_t total = static_cast<size_t>(mc) * out_n;
-        int fgrid = static_cast<int>((total + 255) / 256);
-        if (fgrid > 2048) fgrid = 2048;
-        skinny_finalize_kernel<<<fgrid, 256, 0, st>>>(sk.slab, y + static_cast<size_t>(m0) * out_n, mc, N, sk.KS,
-                                                      SlabScale{wbits == 4 ? nullptr : scale, nullptr, nullptr}, bias,
-                                                      residual ? residual + static_cast<size_t>(m0) * N : nullptr, epi);
+        launch_finalize(sk.slab, y + static_cast<size_t>(m0) * out_n, mc, N, sk.KS, SlabScale{wbits == 4 ? nullptr : scale, nullptr, nullptr}, bias,
+                        residual ? residual + static_cast<size_t>(m0) * N : nullptr, epi, st);
     }
     return launch_status("linear(split-K)");
 }
@@ -408,11 +477,7 @@ int linear_splitk(int wbits, const half_t *x, const void *W, const half_t *scale
 // elementwise consumer of the slabs: y = scale(sum_ks slab) (+bias) (+residual) | SwiGLU over (n, N/2 + n)
 int splitk_finalize(const SplitKSlabs &sk, const SlabScale &sc, half_t *y, int epi, const half_t *bias, const half_t *residual,
                     hipStream_t st) {
-    const int out_n = epi == EPI_SWIGLU ? sk.N / 2 : sk.N;
-    const size_t total = static_cast<size_t>(sk.M) * out_n;
-    int fgrid = static_cast<int>((total + 255) / 256);
-    if (fgrid > 2048) fgrid = 2048;
-    skinny_finalize_kernel<<<fgrid, 256, 0, st>>>(sk.slab, y, sk.M, sk.N, sk.KS, sc, bias, residual, epi);
+    launch_finalize(sk.slab, y, sk.M, sk.N, sk.KS, sc, bias, residual, epi, st);
     return launch_status("linear(split-K finalize)");
 }
 

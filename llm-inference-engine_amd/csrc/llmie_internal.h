@@ -153,6 +153,12 @@ int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, void *k_cache, vo
                           float v_scale = 1.f, const int32_t *block_table = nullptr /* paged cache, see decoder_mha_rope */,
                           int max_pages = 0, int num_pages = 0,
                           int rope_done = 0 /* RoPE + append already done by the QKV projection's epilogue (gemm256_qkv_rope_launch) */);
+// short prefills: slab consumer of the QKV projection with RoPE + KV-cache append folded in (q -> qkv, k / v -> the caches only)
+bool splitk_finalize_qkv_rope_eligible(const SplitKSlabs &sk, int head_size, const void *qkv, const void *bias);
+int splitk_finalize_qkv_rope(const SplitKSlabs &sk, const SlabScale &sc, half_t *qkv, const half_t *qkv_bias, void *k_cache, void *v_cache,
+                             const int32_t *cum_seqlens, const int32_t *history_len, const float2 *rope, int layer, int batch, int head_num,
+                             int kv_head_num, int max_seq_len, int rotary_dim, hipStream_t st, int kv_fp8, float k_scale, float v_scale,
+                             const int32_t *block_table, int max_pages, int num_pages);
 // tok_b[t] / tok_tpos[t] = sequence / cache position (history + position) of packed token t: operands of that epilogue
 // (also copies `args` -- whose tok_b / tok_tpos it fills in -- to args_dev)
 int prefill_token_table(const int32_t *cum_seqlens, const int32_t *history_len, int batch, int num_tokens, int32_t *tok_b, int32_t *tok_tpos,

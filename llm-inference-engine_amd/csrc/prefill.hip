@@ -103,6 +103,118 @@ __global__ __launch_bounds__(256) void prefill_rope_append_kernel(half_t *__rest
     }
 }
 
+// Short prefills (<= 128 tokens: the QKV projection leaves split-K slabs): the slab consumer of the QKV projection with
+// prefill_rope_append_kernel's work folded in -- one launch instead of splitk_finalize + the RoPE / append launch, and the k / v
+// columns never travel through the packed QKV buffer.  Arithmetic per element = skinny_finalize_kernel's (s0 + s1 + ..., scale,
+// one fp16 rounding) followed by prefill_rope_append_kernel's on that fp16 value: bit-identical to the two launches.
+// grid (tokens, ceil(heads / 16)); an item = 4 consecutive dims d .. d + 3 (d < 64) of one head and their rotate-half partners d + 64 ..
+template <bool KV8>
+__global__ __launch_bounds__(256) void splitk_finalize_qkv_rope_kernel(const float *__restrict__ slab, int KS, int M, const SlabScale scale,
+                                                                       half_t *__restrict__ qkv, const half_t *__restrict__ bias,
+                                                                       void *__restrict__ k_cache, void *__restrict__ v_cache,
+                                                                       const int32_t *__restrict__ cum, const int32_t *__restrict__ hist,
+                                                                       const float2 *__restrict__ rope, int batch, int head_num, int kv_head_num,
+                                                                       int max_seq_len, int rotary_dim, size_t layer_off, float k_inv_scale,
+                                                                       float v_inv_scale, const int32_t *__restrict__ table, int max_pages) {
+    constexpr int HS = 128, HALF = 64, GROUPS = HALF / 4;
+    const int t = blockIdx.x;
+    int b, pos;
+    locate_token(cum, batch, t, b, pos);
+    const int tpos = hist[b] + pos;
+    if (tpos < 0 || tpos >= max_seq_len) return;  // never write outside the slab (prefill_rope_append_kernel)
+    const int heads = head_num + 2 * kv_head_num, N = heads * HS;
+    const size_t slab_sz = static_cast<size_t>(M) * N;
+    const float2 *cs = rope + static_cast<size_t>(tpos) * HALF;
+    // blockIdx.y = group of 16 heads: one item per thread, (heads / 16) x tokens workgroups (a single workgroup per token left half
+    // the CUs idle at 128 tokens and walked its 6 items per thread one memory round trip after the other)
+    {
+        const int i = blockIdx.y * 256 + threadIdx.x;
+        if (i >= heads * GROUPS) return;
+        const int h = i / GROUPS, d = (i - h * GROUPS) * 4, n = h * HS + d;
+        floatx4 v[2];
+        for (int k0 = 0; k0 < KS; k0 += 8) {
+            floatx4 p[8][2];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    p[kk][g] = *reinterpret_cast<const floatx4 *>(slab + static_cast<size_t>(min(k0 + kk, KS - 1)) * slab_sz +
+                                                                  static_cast<size_t>(t) * N + n + g * HALF);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+                if (k0 + kk < KS) {
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        if (k0 + kk == 0) v[g] = floatx4{0.f, 0.f, 0.f, 0.f} + p[kk][g];
+                        else v[g] += p[kk][g];
+                    }
+                }
+        }
+        half4_t blo{0, 0, 0, 0}, bhi{0, 0, 0, 0};
+        if (bias) {
+            blo = *reinterpret_cast<const half4_t *>(bias + n);
+            bhi = *reinterpret_cast<const half4_t *>(bias + n + HALF);
+        }
+        const bool rotate = h < head_num + kv_head_num;
+        half4_t olo, ohi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // the projection's output as splitk_finalize stores it (fp16), then prefill_rope_append_kernel's arithmetic
+            const float x0 = to_f32(from_f32<half_t>(scale.apply(v[0][e], t, n + e))) + to_f32(blo[e]);
+            const float x1 = to_f32(from_f32<half_t>(scale.apply(v[1][e], t, n + e + HALF))) + to_f32(bhi[e]);
+            float o0 = x0, o1 = x1;
+            if (rotate && d + e < (rotary_dim >> 1)) {
+                const float2 c = cs[d + e];
+                o0 = x0 * c.x - x1 * c.y;
+                o1 = x1 * c.x + x0 * c.y;
+            }
+            olo[e] = from_f32<half_t>(o0);
+            ohi[e] = from_f32<half_t>(o1);
+        }
+        if (h < head_num) {
+            half_t *dst = qkv + static_cast<size_t>(t) * N + n;
+            *reinterpret_cast<half4_t *>(dst) = olo;
+            *reinterpret_cast<half4_t *>(dst + HALF) = ohi;
+        } else {
+            const bool is_k = h < head_num + kv_head_num;
+            const int g = is_k ? h - head_num : h - head_num - kv_head_num;
+            const size_t off = table ? layer_off + ((static_cast<size_t>(table[static_cast<size_t>(b) * max_pages + tpos / 128]) * kv_head_num + g) * 128 + tpos % 128) * HS
+                                     : layer_off + ((static_cast<size_t>(b) * kv_head_num + g) * max_seq_len + tpos) * HS;
+            if constexpr (KV8) {
+                uint8_t *dst = static_cast<uint8_t *>(is_k ? k_cache : v_cache) + off + d;
+                const float inv = is_k ? k_inv_scale : v_inv_scale;
+                *reinterpret_cast<unsigned *>(dst) = pack4_e4m3(to_f32(olo[0]) * inv, to_f32(olo[1]) * inv, to_f32(olo[2]) * inv, to_f32(olo[3]) * inv);
+                *reinterpret_cast<unsigned *>(dst + HALF) = pack4_e4m3(to_f32(ohi[0]) * inv, to_f32(ohi[1]) * inv, to_f32(ohi[2]) * inv, to_f32(ohi[3]) * inv);
+            } else {
+                half_t *dst = static_cast<half_t *>(is_k ? k_cache : v_cache) + off + d;
+                *reinterpret_cast<half4_t *>(dst) = olo;
+                *reinterpret_cast<half4_t *>(dst + HALF) = ohi;
+            }
+        }
+    }
+}
+bool splitk_finalize_qkv_rope_eligible(const SplitKSlabs &sk, int head_size, const void *qkv, const void *bias) {
+    return head_size == 128 && sk.N % 128 == 0 && reinterpret_cast<uintptr_t>(sk.slab) % 16 == 0 &&
+           (reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(bias)) % 8 == 0;
+}
+int splitk_finalize_qkv_rope(const SplitKSlabs &sk, const SlabScale &sc, half_t *qkv, const half_t *qkv_bias, void *k_cache, void *v_cache,
+                             const int32_t *cum_seqlens, const int32_t *history_len, const float2 *rope, int layer, int batch, int head_num,
+                             int kv_head_num, int max_seq_len, int rotary_dim, hipStream_t st, int kv_fp8, float k_scale, float v_scale,
+                             const int32_t *block_table, int max_pages, int num_pages) {
+    const size_t layer_off = block_table ? static_cast<size_t>(layer) * num_pages * kv_head_num * 128 * 128
+                                         : static_cast<size_t>(layer) * batch * kv_head_num * max_seq_len * 128;
+    const dim3 grid(sk.M, (sk.N / 128 + 15) / 16);
+    if (kv_fp8)
+        splitk_finalize_qkv_rope_kernel<true><<<grid, 256, 0, st>>>(sk.slab, sk.KS, sk.M, sc, qkv, qkv_bias, k_cache, v_cache, cum_seqlens, history_len,
+                                                                    rope, batch, head_num, kv_head_num, max_seq_len, rotary_dim, layer_off,
+                                                                    1.0f / k_scale, 1.0f / v_scale, block_table, max_pages);
+    else
+        splitk_finalize_qkv_rope_kernel<false><<<grid, 256, 0, st>>>(sk.slab, sk.KS, sk.M, sc, qkv, qkv_bias, k_cache, v_cache, cum_seqlens, history_len,
+                                                                     rope, batch, head_num, kv_head_num, max_seq_len, rotary_dim, layer_off, 1.f, 1.f,
+                                                                     block_table, max_pages);
+    return launch_status("splitk_finalize(qkv + rope + append)");
+}
+
 // Per-token (sequence, cache position) table for the QKV projection's fused RoPE + append epilogue (gemm256.cuh
 // g256_store_qkv_rope): tok_b[t] = sequence of packed token t, tok_tpos[t] = history + position.  Once per prefill call.
 __global__ __launch_bounds__(256) void prefill_token_table_kernel(const int32_t *__restrict__ cum, const int32_t *__restrict__ hist, int batch,

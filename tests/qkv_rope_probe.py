@@ -28,6 +28,11 @@ CASES = [
     ("int4_b1", "int4", 16, 16, 1024, [1025], [0], 1152, False, False, False, 128),
     ("fp8_b2", "fp8", 16, 16, 1024, [640, 512], [0, 64], 768, False, False, True, 128),
     ("fp8_kv8_paged", "fp8", 16, 16, 1024, [1200], [0], 1280, True, True, False, 128),
+    # short prefills (<= 128 tokens): the QKV projection's split-K slab consumer does the RoPE + append (splitk_finalize_qkv_rope)
+    ("short_f16_ragged_bias", "f16", 16, 16, 1024, [70, 40, 18], [0, 5, 0], 256, False, False, True, 128),
+    ("short_f16_gqa_paged_kv8", "f16", 16, 4, 1024, [128], [100], 384, True, True, False, 64),
+    ("short_int8_b2", "int8", 16, 16, 1024, [64, 57], [0, 0], 128, False, False, True, 128),
+    ("short_int4_b1", "int4", 16, 16, 1024, [50], [3], 128, False, False, False, 128),
 ]
 
 
