@@ -409,8 +409,17 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
                     mloc = fmaxf(mloc, sacc[tt][e]);
                 }
         }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        // maximum over the 4 lanes of a query row (lanes r, r + 16, r + 32, r + 48) with the gfx950 row-swap instructions (VALU:
+        // v_permlane32_swap hands every lane the value 32 lanes away, v_permlane16_swap the one 16 away) instead of two dependent
+        // ds_bpermute round trips through the LDS crossbar, each behind an lgkmcnt(0) that also drains the wave's fragment reads
+        {
+            const unsigned u0 = __builtin_bit_cast(unsigned, mloc);
+            const auto s32 = __builtin_amdgcn_permlane32_swap(u0, u0, false, false);
+            mloc = fmaxf(__builtin_bit_cast(float, s32[0]), __builtin_bit_cast(float, s32[1]));
+            const unsigned u1 = __builtin_bit_cast(unsigned, mloc);
+            const auto s16 = __builtin_amdgcn_permlane16_swap(u1, u1, false, false);
+            mloc = fmaxf(__builtin_bit_cast(float, s16[0]), __builtin_bit_cast(float, s16[1]));
+        }
         const float m_new = fmaxf(m_run, mloc);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: keep everything at zero
         const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_use);
