@@ -982,7 +982,7 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
     static const bool rope_fuse_off = getenv("LLMIE_NO_QKV_ROPE_FUSION") != nullptr;
     const bool kv8 = c.kv_fmt == LLMIE_KV_FP8;
     const float ksc = (kv8 && c.k_scale > 0.f) ? c.k_scale : 1.f, vsc = (kv8 && c.v_scale > 0.f) ? c.v_scale : 1.f;
-    bool rope_fusable = !rope_fuse_off && T >= kWqPrefillRows && !dec->packed_only && gemm256_fills(T, QKV);
+    bool rope_fusable = !rope_fuse_off && T >= kWqPrefillRows && gemm256_fills(T, QKV);
     if (rope_fusable) {
         QkvRopeArgs ra{};
         ra.k_cache = k_cache;
@@ -1057,11 +1057,17 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
             const llmie_layer_weights &w = dec->layers[l];
             const llmie_decoder::PackedLayer &pw = dec->packed[l];
             TIMED(LLMIE_OP_ATTN_NORM, llmie_rmsnorm(h, resid, w.attn_norm_gamma, c.rms_eps, T, H, LLMIE_F16, stream));
-            TIMED(LLMIE_OP_QKV_GEMM, pproj(pw.qkv, w.qkv.scale, 0, h, qkv, H, QKV, EPI_NONE_, nullptr));
-            TIMED(LLMIE_OP_MHA, prefill_attention_f16(qkv, (const half_t *)w.qkv.bias, k_cache, v_cache, attn, cum, history_lengths,
-                                                      dec->rope_table, l, batch, T, max_q_len, c.head_num, c.kv_head_num, c.head_size,
-                                                      c.max_seq_len, c.rotary_dim, st, c.kv_fmt == LLMIE_KV_FP8, c.k_scale > 0.f ? c.k_scale : 1.f,
-                                                      c.v_scale > 0.f ? c.v_scale : 1.f, dec->page_table, dec->max_pages, dec->num_pages));
+            int fused = 0;
+            if (rope_fusable && reinterpret_cast<uintptr_t>(w.qkv.bias) % 8 == 0 && deq_bytes >= static_cast<size_t>(QKV) * H * sizeof(half_t) &&
+                gemm256_qkv_rope_eligible(0, T, QKV, H, h, deq, nullptr, qkv)) {
+                // (the unpacked fp16 image as the operand of the QKV projection with the RoPE + append epilogue)
+                fused = 1;
+                TIMED(LLMIE_OP_QKV_GEMM, pk_unpack_f16(dec->pk_wf, pw.qkv, static_cast<const half_t *>(w.qkv.scale), static_cast<half_t *>(deq), QKV, H, 0, st));
+                TIMED(LLMIE_OP_QKV_GEMM, qkv_rope(l, w.qkv, 0, h, nullptr, deq, nullptr));
+            } else {
+                TIMED(LLMIE_OP_QKV_GEMM, pproj(pw.qkv, w.qkv.scale, 0, h, qkv, H, QKV, EPI_NONE_, nullptr));
+            }
+            TIMED(LLMIE_OP_MHA, attention(l, w.qkv, fused));
             TIMED(LLMIE_OP_O_GEMM, pproj(pw.o, w.o.scale, 0, attn, h, H, H, EPI_NONE_, nullptr));
             TIMED(LLMIE_OP_FFN_NORM, llmie_fused_add_bias_residual_rmsnorm(resid, h, w.o.bias, w.ffn_norm_gamma, c.rms_eps, T, H, LLMIE_F16, stream));
             if (T <= 192 || gemm256_swiglu_fills(T, 2 * I)) {

@@ -28,6 +28,7 @@ CASES = [
     ("int4_b1", "int4", 16, 16, 1024, [1025], [0], 1152, False, False, False, 128),
     ("fp8_b2", "fp8", 16, 16, 1024, [640, 512], [0, 64], 768, False, False, True, 128),
     ("fp8_kv8_paged", "fp8", 16, 16, 1024, [1200], [0], 1280, True, True, False, 128),
+    ("po_int8_b2", "int8", 16, 16, 1024, [700, 420], [0, 0], 768, False, False, True, 128),        # LLMIE_DEC_PACKED_ONLY: unpacked image + fused epilogue
     # short prefills (<= 128 tokens): the QKV projection's split-K slab consumer does the RoPE + append (splitk_finalize_qkv_rope)
     ("short_f16_ragged_bias", "f16", 16, 16, 1024, [70, 40, 18], [0, 5, 0], 256, False, False, True, 128),
     ("short_f16_gqa_paged_kv8", "f16", 16, 4, 1024, [128], [100], 384, True, True, False, 64),
@@ -69,7 +70,8 @@ for name, wfmt, nh, kvh, I, lens, hist, max_seq, kv8, paged, bias, rot in CASES:
     cfg = dict(head_num=nh, kv_head_num=kvh, head_size=hs, inter_size=I, num_layers=L, vocab_size=100, max_seq_len=max_seq, max_batch=bs,
                rotary_dim=rot, rotary_base=10000.0, rms_eps=1e-5, dtype=llmie.F16,
                wfmt={"f16": llmie.W_F16, "int8": llmie.W_INT8, "int4": llmie.W_INT4, "fp8": llmie.W_FP8}[wfmt], int4_group=128,
-               kv_fmt=llmie.KV_FP8 if kv8 else llmie.KV_NATIVE, k_scale=0.037 if "np2" in name else 1 / 32, v_scale=0.021 if "np2" in name else 1 / 16)
+               kv_fmt=llmie.KV_FP8 if kv8 else llmie.KV_NATIVE, k_scale=0.037 if "np2" in name else 1 / 32, v_scale=0.021 if "np2" in name else 1 / 16,
+               flags=llmie.DEC_PACKED_ONLY if name.startswith("po_") else 0)
     dec = llmie.Decoder(cfg, layers)
     g = torch.Generator(device="cpu").manual_seed(len(name))
     x = torch.randn((T, H), generator=g).to(DEV).to(F16)
