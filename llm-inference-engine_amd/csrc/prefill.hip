@@ -379,14 +379,16 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
         __builtin_amdgcn_sched_barrier(0);
         floatx4 sacc[4];
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) sacc[tt] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
         for (int s = 0; s < 4; ++s)  // 4 independent accumulators per k-step: no back-to-back dependent MFMAs
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) sacc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[tt][s], qf[s], sacc[tt], 0, 0, 0);
+            for (int tt = 0; tt < 4; ++tt)   // (first k-step: the zero C operand is an inline constant, no accumulator to clear)
+                sacc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[tt][s], qf[s], s == 0 ? floatx4{0.f, 0.f, 0.f, 0.f} : sacc[tt], 0, 0, 0);
         // lane holds S[qrow][t = t0 + 16 tt + 4 q + e].  Softmax in the log2 domain: s2 = S * scale * log2(e), p = 2^(s2 - m)
         // (one v_exp_f32 per element, no separate multiply); the causal / length mask is only evaluated on tiles that reach past
         // the wave's first query position or the context end (wave-uniform test), and 2^(-inf) = 0 needs no select.
+        // (VALU diet, round 3: the kernel is bound by VALU ISSUE -- ~330 VALU slots per wave and tile against 32 MFMAs, two waves
+        // per SIMD)  The row maximum is taken over the RAW logits and scaled once (scale2 > 0), the scale rides in
+        // the exponent's FMA, numerators are converted to fp16 in pairs.
         const float scale2 = scale * 1.44269504088896341f;
         const bool need_mask = t0 + BT - 1 > history + q0 + wave * 16 || t0 + BT > ctx;
         float mloc = -INFINITY;
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int t = t0 + tt * 16 + 4 * q + e;
-                    const float v = (t <= qpos && t < ctx) ? sacc[tt][e] * scale2 : -INFINITY;
+                    const float v = (t <= qpos && t < ctx) ? sacc[tt][e] : -INFINITY;
                     sacc[tt][e] = v;
                     mloc = fmaxf(mloc, v);
                 }
@@ -404,10 +406,7 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    sacc[tt][e] *= scale2;
-                    mloc = fmaxf(mloc, sacc[tt][e]);
-                }
+                for (int e = 0; e < 4; ++e) mloc = fmaxf(mloc, sacc[tt][e]);
         }
         // maximum over the 4 lanes of a query row (lanes r, r + 16, r + 32, r + 48) with the gfx950 row-swap instructions (VALU:
         // v_permlane32_swap hands every lane the value 32 lanes away, v_permlane16_swap the one 16 away) instead of two dependent
@@ -420,18 +419,24 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
             const auto s16 = __builtin_amdgcn_permlane16_swap(u1, u1, false, false);
             mloc = fmaxf(__builtin_bit_cast(float, s16[0]), __builtin_bit_cast(float, s16[1]));
         }
+        mloc *= scale2;   // (-inf stays -inf)
         const float m_new = fmaxf(m_run, mloc);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: keep everything at zero
         const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_use);
         float lsum = 0.f;
         half8_t pf[2];  // P^T fragments = MFMA B operand of the two 32-key steps
+        typedef float float2v_t __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float p = __builtin_amdgcn_exp2f(sacc[tt][e] - m_use);
-                lsum += p;
-                pf[tt >> 1][(tt & 1) * 4 + e] = from_f32<half_t>(p);
+            for (int e = 0; e < 4; e += 2) {
+                // p = 2^(s * scale2 - m): one FMA + one v_exp_f32 per element (2^(-inf) = 0 for masked keys)
+                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[tt][e], scale2, -m_use));
+                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[tt][e + 1], scale2, -m_use));
+                lsum += p0 + p1;
+                const half2_t h = __builtin_convertvector(float2v_t{p0, p1}, half2_t);   // v_cvt_pk_f16_f32 (round to nearest even)
+                pf[tt >> 1][(tt & 1) * 4 + e] = h[0];
+                pf[tt >> 1][(tt & 1) * 4 + e + 1] = h[1];
             }
         // l_run is this lane's PARTIAL row sum (its 16 of the tile's 64 keys): alpha is the same for the 4 lanes of a row, so the
         // cross-lane reduction is linear and done once after the last tile instead of two LDS-path shuffles per tile
@@ -458,9 +463,8 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
             }
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) {
-                const half8_t vf = {static_cast<half_t>(lo[dt][0]), static_cast<half_t>(lo[dt][1]), static_cast<half_t>(lo[dt][2]),
-                                    static_cast<half_t>(lo[dt][3]), static_cast<half_t>(hi[dt][0]), static_cast<half_t>(hi[dt][1]),
-                                    static_cast<half_t>(hi[dt][2]), static_cast<half_t>(hi[dt][3])};
+                struct V8 { fp16x4_t lo, hi; };   // the two transposed reads side by side ARE the 8-half A operand: no repacking
+                const half8_t vf = __builtin_bit_cast(half8_t, V8{lo[dt], hi[dt]});
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[c], o[dt], 0, 0, 0);
             }
         }
