@@ -19,6 +19,15 @@
 namespace llmie {
 
 
+#ifdef FLASH_STAMPS   // diagnostic build only (tools/micro/flash_probe.hip): where a wave's cycles go inside one key tile; never defined in the product build
+__device__ unsigned long long flash_stamp_buf[64 * 8 * 8];   // [workgroup < 64][wave][segment]: shader-clock cycles summed over the tiles
+#define FLASH_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define FLASH_ACC(i, a, b) stamp_acc[i] += (b) - (a)
+#else
+#define FLASH_T(var) do { } while (0)
+#define FLASH_ACC(i, a, b) do { } while (0)
+#endif
+
 // token -> (batch, position in its sequence) from the exclusive prefix cum[batch+1]
 __device__ __forceinline__ void locate_token(const int32_t *__restrict__ cum, int batch, int t, int &b, int &pos) {
     int lo = 0;
@@ -352,17 +361,27 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
             *reinterpret_cast<half8_t *>(Vsb[buf] + row * VSTRIDE + ch * 8) = vvv;
         }
     };
+#ifdef FLASH_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     fetch_tile(0);
     publish_tile(0);
     if (BT < t_hi) fetch_tile(BT);
     for (int t0 = 0, it = 0; t0 < t_hi; t0 += BT, ++it) {
         const half_t *Ks = Ksb[it & 1], *Vs = Vsb[it & 1];
+        FLASH_T(ta);
         __syncthreads();  // tile `it` published by every thread; every wave done with tile it-1 (the other buffer)
+        FLASH_T(tb);
+        FLASH_ACC(0, ta, tb);
+#ifndef FLASH_SKIP_STAGE   // (timing experiment only, wrong results: no staging inside the loop)
         if (t0 + BT < t_hi) {
             publish_tile((it + 1) & 1);                        // tile it+1: registers (fetched last iteration) -> other buffer
             if (t0 + 2 * BT < t_hi) fetch_tile(t0 + 2 * BT);   // tile it+2: in flight under this iteration's MFMAs
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);  // keep the loads above the compute below
+        FLASH_T(tc);
+        FLASH_ACC(1, tb, tc);
         // key tiles entirely in the future of this wave's 16 query rows are skipped by the whole wave (it still takes part in
         // the staging and the barriers above)
         if (t0 > history + q0 + wave * 16 + 15) continue;
@@ -373,6 +392,13 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
             const int row = tt * 16 + r;
+#ifdef FLASH_SKIP_K   // timing experiment only (wrong results): half of the K fragment reads
+            if (tt >= 2) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) kfr[tt][s] = kfr[tt - 2][s];
+                continue;
+            }
+#endif
 #pragma unroll
             for (int s = 0; s < 4; ++s) kfr[tt][s] = *reinterpret_cast<const half8_t *>(Ks + row * HS + (((s * 4 + q) ^ (row & 15)) << 3));
         }
@@ -386,6 +412,13 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
         // lane holds S[qrow][t = t0 + 16 tt + 4 q + e].  Softmax in the log2 domain: s2 = S * scale * log2(e), p = 2^(s2 - m)
         // (one v_exp_f32 per element, no separate multiply); the causal / length mask is only evaluated on tiles that reach past
         // the wave's first query position or the context end (wave-uniform test), and 2^(-inf) = 0 needs no select.
+#ifdef FLASH_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(sacc[0]), "+v"(sacc[1]), "+v"(sacc[2]), "+v"(sacc[3]));
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // (MFMA results written: the next read of them would wait anyway)
+#endif
+        FLASH_T(td);
+        FLASH_ACC(2, tc, td);
         // (VALU diet, round 3: the kernel is bound by VALU ISSUE -- ~330 VALU slots per wave and tile against 32 MFMAs, two waves
         // per SIMD)  The row maximum is taken over the RAW logits and scaled once (scale2 > 0), the scale rides in
         // the exponent's FMA, numerators are converted to fp16 in pairs.
@@ -419,6 +452,41 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
             const auto s16 = __builtin_amdgcn_permlane16_swap(u1, u1, false, false);
             mloc = fmaxf(__builtin_bit_cast(float, s16[0]), __builtin_bit_cast(float, s16[1]));
         }
+#ifdef FLASH_SKIP_SOFTMAX   // (timing experiment only, wrong results: numerators = raw logits, no exponentials)
+        {
+            float lsum = 0.f;
+            half8_t pf[2];
+            typedef float float2v_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const half2_t h = __builtin_convertvector(float2v_t{sacc[tt][e], sacc[tt][e + 1]}, half2_t);
+                    pf[tt >> 1][(tt & 1) * 4 + e] = h[0];
+                    pf[tt >> 1][(tt & 1) * 4 + e + 1] = h[1];
+                }
+            l_run += mloc;
+            typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+            typedef __attribute__((address_space(3))) fp16x4_t *lds_fp16x4_ptr;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const half_t *blk = Vs + (32 * c + 4 * q + (r >> 2)) * VSTRIDE + 4 * (r & 3);
+                fp16x4_t lo[8], hi[8];
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) {
+                    lo[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4_ptr)(blk + dt * 16));
+                    hi[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4_ptr)(blk + 16 * VSTRIDE + dt * 16));
+                }
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) {
+                    struct V8 { fp16x4_t lo, hi; };
+                    const half8_t vf = __builtin_bit_cast(half8_t, V8{lo[dt], hi[dt]});
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[c], o[dt], 0, 0, 0);
+                }
+            }
+            continue;
+        }
+#endif
         mloc *= scale2;   // (-inf stays -inf)
         const float m_new = fmaxf(m_run, mloc);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: keep everything at zero
@@ -447,6 +515,11 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) o[dt] *= alpha;
         }
+#ifdef FLASH_STAMPS
+        asm volatile("" : "+v"(pf[0]), "+v"(pf[1]));
+#endif
+        FLASH_T(te);
+        FLASH_ACC(3, td, te);
         // ---- O^T += V^T . P^T : A fragment = V[t(q,j)][d = 16 dt + r] gathered down a column ----
         // lane (r, q) of its 16-lane group supplies the address of block row (r >> 2), columns 4 (r & 3) .. +3, and receives
         // column r of the block's 4 rows; all 16 transposed reads of a 32-key step are issued before its 8 MFMAs
@@ -459,7 +532,11 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) {
                 lo[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4_ptr)(blk + dt * 16));
+#ifdef FLASH_SKIP_V   // timing experiment only (wrong results): half of the V^T fragment reads
+                hi[dt] = lo[dt];
+#else
                 hi[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4_ptr)(blk + 16 * VSTRIDE + dt * 16));
+#endif
             }
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) {
@@ -468,7 +545,19 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[c], o[dt], 0, 0, 0);
             }
         }
+#ifdef FLASH_STAMPS
+        asm volatile("" : "+v"(o[0]), "+v"(o[7]));
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+#endif
+        FLASH_T(tf);
+        FLASH_ACC(4, te, tf);
+        FLASH_ACC(5, ta, tf);
     }
+#ifdef FLASH_STAMPS
+    if (lane == 0 && lin < 64) {
+        for (int i = 0; i < 8; ++i) flash_stamp_buf[(lin * 8 + wave) * 8 + i] = stamp_acc[i];
+    }
+#endif
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
     if (qrow < len) {
