@@ -337,7 +337,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
     auto rotate = [&](float (&x)[N]) {
 #pragma unroll
         for (int e = 0; e < N; ++e) {
-            const float partner = __shfl_xor(x[e], LPT / 2, 64);
+            const float partner = (LPT / 2 < 16) ? lane_xor_lt16<(LPT / 2 < 16 ? LPT / 2 : 8)>(x[e]) : __shfl_xor(x[e], LPT / 2, 64);
             x[e] = x[e] * rc[e] + partner * rs[e];
         }
     };
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
 #pragma unroll
     for (int r = 0; r < REP; ++r) {
 #pragma unroll
-        for (int o = LPT; o < 64; o <<= 1) cm[r] = fmaxf(cm[r], __shfl_xor(cm[r], o, 64));
+        for (int o = LPT; o < 64; o <<= 1) cm[r] = lane_xor_max_o(cm[r], o);
         const float mnew = fmaxf(mx[r], cm[r]);
         if (!first) {
             const float f = (mx[r] == -INFINITY) ? 0.f : __expf(mx[r] - mnew);
@@ -530,9 +530,10 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_split_kernel(
     for (int r = 0; r < REP; ++r) {
 #pragma unroll
         for (int o = LPT; o < 64; o <<= 1) {
-            ls[r] += __shfl_xor(ls[r], o, 64);
+            // (v + v[lane ^ o] through the row swaps / DPP: no LDS round trips; bit-identical to the __shfl_xor butterfly)
+            ls[r] = lane_xor_sum_o(ls[r], o);
 #pragma unroll
-            for (int e = 0; e < N; ++e) acc[r][e] += __shfl_xor(acc[r][e], o, 64);
+            for (int e = 0; e < N; ++e) acc[r][e] = lane_xor_sum_o(acc[r][e], o);
         }
     }
     // ---- merge the 4 waves through LDS ----

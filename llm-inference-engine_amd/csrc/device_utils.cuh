@@ -54,10 +54,88 @@ __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_or<0x143, 0xC>(v, v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
-// reduce within groups of `width` consecutive lanes (width power of two <= 64)
+// ---- exact xor-lane exchanges without the LDS crossbar (round 3).  __shfl_xor lowers to ds_bpermute_b32: an LDS-path round trip
+// of ~100+ cycles behind an lgkmcnt wait that also drains every other LDS / scalar-memory access of the wave; the decode attention
+// kernel held 68 of them, several of them in dependent chains.  All 64 lanes must be active at the call.
+//   xor 1, 2: DPP quad_perm;  xor 4: DPP row_shl:4 into banks 0 / 2 + row_shr:4 into banks 1 / 3;  xor 8: DPP row_ror:8;
+//   xor 16, 32: the gfx950 row swaps v_permlane16_swap / v_permlane32_swap (both registers of the swap hold v: afterwards one
+//   holds the lane's own-or-partner row, the other the other one -- enough for commutative reductions, see lane_xor_sum / _max).
+template <int O> __device__ __forceinline__ float lane_xor_lt16(float v) {
+    static_assert(O == 1 || O == 2 || O == 4 || O == 8, "DPP forms: xor 1, 2, 4, 8");
+    const int x = __builtin_bit_cast(int, v);
+    int r;
+    if constexpr (O == 1) r = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);
+    else if constexpr (O == 2) r = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);
+    else if constexpr (O == 8) r = __builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false);   // row_ror:8 = lane ^ 8 inside a row of 16
+    else {
+        r = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);   // row_shl:4 -> lanes 0-3, 8-11 of every row take lane + 4
+        r = __builtin_amdgcn_update_dpp(r, x, 0x114, 0xF, 0xA, false);   // row_shr:4 -> lanes 4-7, 12-15 take lane - 4
+    }
+    return __builtin_bit_cast(float, r);
+}
+// hipcc (ROCm 7.2) mis-lowers the SECOND result of __builtin_amdgcn_permlane{16,32}_swap: both elements of the returned pair come
+// out of the first register -- `max(s[0], s[1])` compiled to `s[0]`, "the value of the lane's even row", no maximum at all (found
+// with tools/micro/lane_xor_check.hip; the flash prefill kernel had run for a few hours on a row "maximum" that was merely the
+// same for the four lanes of a row -- mathematically still a valid softmax stabiliser, but no bound on the numerators).  An empty
+// asm on both extracted values makes the register allocator hand out the second register; the check tool and
+// tests/test_abi_cpu.py (disassembly: every row swap is followed by an instruction that reads BOTH of its registers) pin it.
+template <int O> __device__ __forceinline__ void lane_row_swap(float v, float &a, float &b) {
+    static_assert(O == 16 || O == 32, "row swaps: distance 16 or 32");
+    unsigned x = __builtin_bit_cast(unsigned, v), y = x;
+    asm volatile("" : "+v"(y));
+    const auto s = O == 16 ? __builtin_amdgcn_permlane16_swap(x, y, false, false) : __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    unsigned ua = s[0], ub = s[1];
+    asm volatile("" : "+v"(ua), "+v"(ub));
+    a = __builtin_bit_cast(float, ua);
+    b = __builtin_bit_cast(float, ub);
+}
+// v[lane] + v[lane ^ O] / max(v[lane], v[lane ^ O]) in every lane, O a power of two < 64: the operands of the xor butterfly, so
+// the results are bit-identical to the __shfl_xor forms (fp add and max are commutative)
+template <int O> __device__ __forceinline__ float lane_xor_sum(float v) {
+    if constexpr (O < 16) return v + lane_xor_lt16<O>(v);
+    else {
+        float a, b;
+        lane_row_swap<O>(v, a, b);
+        return a + b;
+    }
+}
+template <int O> __device__ __forceinline__ float lane_xor_max(float v) {
+    if constexpr (O < 16) return fmaxf(v, lane_xor_lt16<O>(v));
+    else {
+        float a, b;
+        lane_row_swap<O>(v, a, b);
+        return fmaxf(a, b);
+    }
+}
+// the same for a distance known after unrolling (o in {1, 2, 4, 8, 16, 32})
+__device__ __forceinline__ float lane_xor_sum_o(float v, int o) {
+    switch (o) {
+        case 1: return lane_xor_sum<1>(v);
+        case 2: return lane_xor_sum<2>(v);
+        case 4: return lane_xor_sum<4>(v);
+        case 8: return lane_xor_sum<8>(v);
+        case 16: return lane_xor_sum<16>(v);
+        default: return lane_xor_sum<32>(v);
+    }
+}
+__device__ __forceinline__ float lane_xor_max_o(float v, int o) {
+    switch (o) {
+        case 1: return lane_xor_max<1>(v);
+        case 2: return lane_xor_max<2>(v);
+        case 4: return lane_xor_max<4>(v);
+        case 8: return lane_xor_max<8>(v);
+        case 16: return lane_xor_max<16>(v);
+        default: return lane_xor_max<32>(v);
+    }
+}
+// reduce within groups of `width` consecutive lanes (width power of two <= 64): the xor butterfly, largest distance first
 template <int WIDTH> __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if constexpr (WIDTH >= 64) v = lane_xor_sum<32>(v);
+    if constexpr (WIDTH >= 32) v = lane_xor_sum<16>(v);
+    if constexpr (WIDTH >= 16) v = lane_xor_sum<8>(v);
+    if constexpr (WIDTH >= 8) v = lane_xor_sum<4>(v);
+    if constexpr (WIDTH >= 4) v = lane_xor_sum<2>(v);
+    if constexpr (WIDTH >= 2) v = lane_xor_sum<1>(v);
     return v;
 }
 

@@ -442,51 +442,9 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
                 for (int e = 0; e < 4; ++e) mloc = fmaxf(mloc, sacc[tt][e]);
         }
         // maximum over the 4 lanes of a query row (lanes r, r + 16, r + 32, r + 48) with the gfx950 row-swap instructions (VALU:
-        // v_permlane32_swap hands every lane the value 32 lanes away, v_permlane16_swap the one 16 away) instead of two dependent
-        // ds_bpermute round trips through the LDS crossbar, each behind an lgkmcnt(0) that also drains the wave's fragment reads
-        {
-            const unsigned u0 = __builtin_bit_cast(unsigned, mloc);
-            const auto s32 = __builtin_amdgcn_permlane32_swap(u0, u0, false, false);
-            mloc = fmaxf(__builtin_bit_cast(float, s32[0]), __builtin_bit_cast(float, s32[1]));
-            const unsigned u1 = __builtin_bit_cast(unsigned, mloc);
-            const auto s16 = __builtin_amdgcn_permlane16_swap(u1, u1, false, false);
-            mloc = fmaxf(__builtin_bit_cast(float, s16[0]), __builtin_bit_cast(float, s16[1]));
-        }
-#ifdef FLASH_SKIP_SOFTMAX   // (timing experiment only, wrong results: numerators = raw logits, no exponentials)
-        {
-            float lsum = 0.f;
-            half8_t pf[2];
-            typedef float float2v_t __attribute__((ext_vector_type(2)));
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-                for (int e = 0; e < 4; e += 2) {
-                    const half2_t h = __builtin_convertvector(float2v_t{sacc[tt][e], sacc[tt][e + 1]}, half2_t);
-                    pf[tt >> 1][(tt & 1) * 4 + e] = h[0];
-                    pf[tt >> 1][(tt & 1) * 4 + e + 1] = h[1];
-                }
-            l_run += mloc;
-            typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
-            typedef __attribute__((address_space(3))) fp16x4_t *lds_fp16x4_ptr;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const half_t *blk = Vs + (32 * c + 4 * q + (r >> 2)) * VSTRIDE + 4 * (r & 3);
-                fp16x4_t lo[8], hi[8];
-#pragma unroll
-                for (int dt = 0; dt < 8; ++dt) {
-                    lo[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4_ptr)(blk + dt * 16));
-                    hi[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4_ptr)(blk + 16 * VSTRIDE + dt * 16));
-                }
-#pragma unroll
-                for (int dt = 0; dt < 8; ++dt) {
-                    struct V8 { fp16x4_t lo, hi; };
-                    const half8_t vf = __builtin_bit_cast(half8_t, V8{lo[dt], hi[dt]});
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[c], o[dt], 0, 0, 0);
-                }
-            }
-            continue;
-        }
-#endif
+        // v_permlane32_swap pairs every lane with the one 32 lanes away, v_permlane16_swap with the one 16 away) instead of two
+        // dependent ds_bpermute round trips through the LDS crossbar, each behind an lgkmcnt(0) that also drains the wave's fragment reads
+        mloc = lane_xor_max<16>(lane_xor_max<32>(mloc));   // (device_utils.cuh)
         mloc *= scale2;   // (-inf stays -inf)
         const float m_new = fmaxf(m_run, mloc);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: keep everything at zero

@@ -118,3 +118,59 @@ def test_eight_phase_gemm_kernels_do_not_spill():
     assert len(ks) >= 10, [k["name"] for k in ks]
     bad = [k for k in ks if k["vgpr_spill"] or k["sgpr_spill"] or k["scratch"] or k["vgpr"] > 256]
     assert not bad, bad
+
+
+def test_row_swaps_use_both_result_registers():
+    """v_permlane16_swap / v_permlane32_swap (gfx950) exchange rows between TWO registers.  hipcc (ROCm 7.2) mis-lowers the second
+    element of the builtin's result pair (both elements read the first register): `max(s[0], s[1])` silently became `s[0]`
+    (device_utils.cuh lane_row_swap carries the workaround; tools/micro/lane_xor_check.hip checks the values on the GPU).  Here,
+    on the built objects: the signature of the collapse -- the swap's SECOND register overwritten right behind the swap without having
+    been read (`v_permlane32_swap v109, v110; v_mov v110, v109`) -- must not occur."""
+    import glob
+    import os
+    import re
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    llvm = "/opt/rocm/lib/llvm/bin/"
+    swaps = 0
+    for obj in sorted(glob.glob(os.path.join(root, "llm-inference-engine_amd", "csrc", "_obj", "*.hip.o"))):
+        with tempfile.TemporaryDirectory() as td:
+            fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "dev.co")
+            if subprocess.run([llvm + "llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj, os.path.join(td, "x")],
+                              capture_output=True).returncode != 0:
+                continue   # (a translation unit without device code)
+            subprocess.check_call([llvm + "clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat,
+                                   "--output=" + co, "--unbundle"])
+            lines = [l.split("//")[0].strip() for l in subprocess.check_output([llvm + "llvm-objdump", "-d", co], text=True).splitlines()]
+        lines = [l for l in lines if l and not l.endswith(":")]
+
+        def regs(tok):   # v12 -> {12}; v[8:11] -> {8..11}
+            m = re.fullmatch(r"v(\d+)", tok)
+            if m:
+                return {int(m.group(1))}
+            m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+            return set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()
+
+        for i, l in enumerate(lines):
+            m = re.match(r"v_permlane(16|32)_swap_b32\S*\s+v(\d+),\s*v(\d+)", l)
+            if not m:
+                continue
+            swaps += 1
+            second = int(m.group(3))
+            verdict = True   # (nothing conclusive within the window -- far uses, control flow -- is not the collapse signature)
+            for nxt in lines[i + 1:i + 13]:
+                parts = nxt.split(None, 1)
+                if len(parts) < 2 or parts[0].startswith(("s_", "ds_write", "global_store", "buffer_store")) and "v" not in parts[1]:
+                    continue
+                ops = [t.strip() for t in re.split(r",\s*", parts[1].split(" row_")[0].split(" quad_perm")[0])]
+                writes_first = not parts[0].startswith(("global_store", "ds_write", "buffer_store", "scratch_store", "v_cmp", "s_"))
+                srcs = ops[1:] if writes_first else ops
+                if any(second in regs(t.split(" ")[0]) for t in srcs):
+                    verdict = True
+                    break
+                if writes_first and ops and second in regs(ops[0].split(" ")[0]):
+                    verdict = False
+                    break
+            assert verdict, "%s: the second register of `%s` is overwritten or never read: the swap's result pair collapsed" % (os.path.basename(obj), l)
+    assert swaps >= 4, swaps   # (flash prefill: 2 per instantiation; decode attention: many)
