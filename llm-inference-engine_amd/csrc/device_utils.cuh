@@ -107,6 +107,17 @@ template <int O> __device__ __forceinline__ float lane_xor_max(float v) {
         return fmaxf(a, b);
     }
 }
+// the partner's value itself, any distance (one select more than the combined forms for 16 / 32): for arg-max style butterflies
+template <int O> __device__ __forceinline__ float lane_xor(float v) {
+    if constexpr (O < 16) return lane_xor_lt16<O>(v);
+    else {
+        float a, b;   // a = the even row's (lower half's) value of the lane's pair, b = the odd row's (upper half's)
+        lane_row_swap<O>(v, a, b);
+        const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        return (lane & O) ? a : b;
+    }
+}
+template <int O> __device__ __forceinline__ int lane_xor(int v) { return __builtin_bit_cast(int, lane_xor<O>(__builtin_bit_cast(float, v))); }
 // the same for a distance known after unrolling (o in {1, 2, 4, 8, 16, 32})
 __device__ __forceinline__ float lane_xor_sum_o(float v, int o) {
     switch (o) {
@@ -126,6 +137,16 @@ __device__ __forceinline__ float lane_xor_max_o(float v, int o) {
         case 8: return lane_xor_max<8>(v);
         case 16: return lane_xor_max<16>(v);
         default: return lane_xor_max<32>(v);
+    }
+}
+template <typename V> __device__ __forceinline__ V lane_xor_o(V v, int o) {
+    switch (o) {
+        case 1: return lane_xor<1>(v);
+        case 2: return lane_xor<2>(v);
+        case 4: return lane_xor<4>(v);
+        case 8: return lane_xor<8>(v);
+        case 16: return lane_xor<16>(v);
+        default: return lane_xor<32>(v);
     }
 }
 // reduce within groups of `width` consecutive lanes (width power of two <= 64): the xor butterfly, largest distance first

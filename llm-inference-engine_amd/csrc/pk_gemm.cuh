@@ -504,8 +504,8 @@ __device__ __forceinline__ void pk_phase(const PkArgs &a, const int bx, const in
         if (a.gamma) {
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
-                ss[t] += __shfl_xor(ss[t], 16, 64);
-                ss[t] += __shfl_xor(ss[t], 32, 64);
+                ss[t] = lane_xor_sum<16>(ss[t]);   // (row swaps: no LDS round trip; device_utils.cuh)
+                ss[t] = lane_xor_sum<32>(ss[t]);
                 if (q == 0) stat[(wave * MT + t) * 16 + r] = ss[t];
             }
             pk_barrier();
@@ -580,8 +580,8 @@ __device__ __forceinline__ void pk_phase(const PkArgs &a, const int bx, const in
                 for (int s2 = 0; s2 < SPB; ++s2)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(to_f32(xfrag(xw[u][s2][t])[e])));
-            amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
-            amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+            amax = lane_xor_max<16>(amax);
+            amax = lane_xor_max<32>(amax);
             if (q == 0) amx[(wave * MT + t) * 16 + r] = amax;
         }
         pk_barrier();

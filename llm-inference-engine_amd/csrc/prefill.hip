@@ -516,8 +516,8 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
         for (int i = 0; i < 8; ++i) flash_stamp_buf[(lin * 8 + wave) * 8 + i] = stamp_acc[i];
     }
 #endif
-    l_run += __shfl_xor(l_run, 16, 64);
-    l_run += __shfl_xor(l_run, 32, 64);
+    l_run = lane_xor_sum<16>(l_run);
+    l_run = lane_xor_sum<32>(l_run);
     if (qrow < len) {
         const float inv = v_rem / (l_run + 1e-6f);  // the reference's denominator epsilon (scale_and_mask_and_softmax.cu:118)
         half_t *optr = out + (static_cast<size_t>(cum[b] + qrow) * head_num + h) * HS;

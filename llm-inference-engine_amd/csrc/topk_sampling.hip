@@ -63,8 +63,8 @@ __device__ __forceinline__ void block_select(TopList<KMAX> &tl, int K, int32_t *
         int bi = tl.id[0];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
+            const float ov = lane_xor_o(bv, o);   // (DPP / row swaps: no LDS round trip; device_utils.cuh)
+            const int oi = lane_xor_o(bi, o);
             if (better(ov, oi, bv, bi)) {
                 bv = ov;
                 bi = oi;
@@ -246,8 +246,8 @@ __global__ __launch_bounds__(64) void decode_tail_kernel(const int32_t *__restri
             int bi = tl.id[0];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(bv, o, 64);
-                const int oi = __shfl_xor(bi, o, 64);
+                const float ov = lane_xor_o(bv, o);   // (DPP / row swaps: no LDS round trip; device_utils.cuh)
+                const int oi = lane_xor_o(bi, o);
                 if (better(ov, oi, bv, bi)) {
                     bv = ov;
                     bi = oi;
