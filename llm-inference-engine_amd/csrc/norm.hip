@@ -235,13 +235,54 @@ __global__ __launch_bounds__(256) void rmsnorm_oop_kernel(const half_t *__restri
         }
     }
 }
+// One WAVE per row (round 3): hidden <= 4096 -> at most 8 sixteen-byte vectors per lane, all loads of the row in flight at once,
+// the sum of squares reduced on DPP -- no LDS, no barrier, four rows per workgroup (a quarter of the workgroups of the
+// row-per-workgroup form above, whose two barriers and 2048 eight-KiB workgroups made a 32 MB pass take 9.6 us at 2048 tokens).
+template <int NV>
+__global__ __launch_bounds__(256) void rmsnorm_oop_wave_kernel(const half_t *__restrict__ x, half_t *__restrict__ y,
+                                                               const half_t *__restrict__ gamma, float eps, int hidden, int tokens) {
+    const int lane = threadIdx.x & 63, row_i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row_i >= tokens) return;   // (whole waves: no barrier in this kernel)
+    const int nvec = hidden / 8;
+    const size_t row = static_cast<size_t>(row_i) * hidden;
+    const half8_t *xv = reinterpret_cast<const half8_t *>(x + row);
+    half8_t *yv = reinterpret_cast<half8_t *>(y + row);
+    const half8_t *gv = reinterpret_cast<const half8_t *>(gamma);
+    half8_t keep[NV], g[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = min(lane + j * 64, nvec - 1);   // (clamped: a vector past the row end is loaded twice and not counted)
+        keep[j] = xv[i];
+        g[j] = gv[i];
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+        if (lane + j * 64 < nvec) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += to_f32(keep[j][e]) * to_f32(keep[j][e]);
+        }
+    ss = wave_sum(ss);
+    const float inv = rsqrtf(ss / static_cast<float>(hidden) + eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+        if (lane + j * 64 < nvec) {
+            half8_t v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = from_f32<half_t>(to_f32(keep[j][e]) * to_f32(g[j][e]) * inv);
+            yv[lane + j * 64] = v;
+        }
+}
 bool rmsnorm_oop_eligible(int hidden) { return hidden % 8 == 0 && hidden / 8 <= 1024; }
 int rmsnorm_oop_f16(const half_t *x, half_t *y, const half_t *gamma, float eps, int tokens, int hidden, hipStream_t st) {
     if (!rmsnorm_oop_eligible(hidden) || (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma)) % 16) {
         set_error("rmsnorm (out of place): hidden %d / alignment not supported", hidden);
         return LLMIE_ERR_UNSUPPORTED;
     }
-    rmsnorm_oop_kernel<<<tokens, 256, 0, st>>>(x, y, gamma, eps, hidden);
+    const int nvec = hidden / 8;
+    if (nvec <= 256) rmsnorm_oop_wave_kernel<4><<<(tokens + 3) / 4, 256, 0, st>>>(x, y, gamma, eps, hidden, tokens);
+    else if (nvec <= 512) rmsnorm_oop_wave_kernel<8><<<(tokens + 3) / 4, 256, 0, st>>>(x, y, gamma, eps, hidden, tokens);
+    else rmsnorm_oop_kernel<<<tokens, 256, 0, st>>>(x, y, gamma, eps, hidden);
     return launch_status("rmsnorm(out of place)");
 }
 
