@@ -72,6 +72,36 @@ def test_prefill_matches_oracle(llmie, name, nh, kvh, I, L, lens, hist):
     dec.close()
 
 
+def test_prefill_with_peaked_attention_rows(llmie):
+    """Softmax rows with a large spread of logits (QKV weights scaled so that |q . k| / sqrt(d) reaches the tens, i.e. dozens of
+    powers of two between the keys of one row): the flash kernel's numerators are fp16, so its running row maximum must be a TRUE
+    maximum over all four lanes of a row -- with a merely consistent stabiliser (what a mis-lowered row swap produced for a few
+    hours of round 3: the local maximum of one lane's 16 keys) numerators far above 1 overflow to inf and the output is NaN."""
+    rng = np.random.default_rng(47)
+    nh, kvh, hs, I, L, max_seq = 8, 8, 128, 512, 1, 384
+    H, lens, hist = nh * hs, [300, 77], [0, 5]
+    bs, T = len(lens), int(sum(lens))
+    layers = _model(rng, nh, kvh, hs, I, L)
+    layers[0]["qkv"][: 2 * nh * hs] *= np.float32(5.0)   # q and k rows x 5: logits x 25
+    layers[0]["qkv"] = _h(layers[0]["qkv"])
+    dec = _engine(llmie, layers, nh, kvh, hs, I, max_seq, bs)
+    x = _h(rng.standard_normal((T, H)).astype(np.float32))
+    kc = _h(rng.standard_normal((L, bs, kvh, max_seq, hs)).astype(np.float32) * 2.0)
+    vc = _h(rng.standard_normal((L, bs, kvh, max_seq, hs)).astype(np.float32) * 0.5)
+    kd, vd = torch.from_numpy(kc).to(DEV).to(F16), torch.from_numpy(vc).to(DEV).to(F16)
+    xd = torch.from_numpy(x).to(DEV).to(F16)
+    out = torch.empty_like(xd)
+    dec.prefill(xd, out, kd, vd, torch.tensor(lens, dtype=torch.int32, device=DEV), torch.tensor(hist, dtype=torch.int32, device=DEV), max(lens))
+    exp = oracle_prefill(layers, x, kc, vc, np.array(lens, np.int32), np.array(hist, np.int32), nh, kvh, hs, I, max_seq)
+    got = out.float().cpu().numpy()
+    assert np.isfinite(got).all(), "non-finite outputs: %d" % int((~np.isfinite(got)).sum())
+    # a peaked softmax amplifies the fp16 rounding of q and k (logits of +-40 move by ~0.02): looser than the smooth cases, still
+    # far below what a wrong normalisation gives
+    fro, _ = systematic_error(got, exp)
+    assert fro <= 2e-2, "relative Frobenius error %.3g" % fro
+    dec.close()
+
+
 def _quantise(w, fmt, group=128):
     """numpy definition of the engine's quantisers (tests/test_quant_gpu.py checks the device quantisers against it bit for bit):
     returns (codes, scales, de-quantised fp32 weights)"""
