@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Development tool: long race screen of the eight-phase GEMM kernels (gemm8p.cuh) -- every launch of a shape must reproduce the first
 one bit for bit (fixed accumulation order); fp16 plain / residual / SwiGLU and e4m3, both tile widths, with a cache-thrashing fill and
-a concurrent copy stream perturbing the DMA timing.   python tools/gemm8p_soak.py [launches per shape]"""
+a concurrent copy stream perturbing the DMA timing; round 3: the ROPE forms through whole prefill passes of one 7B-geometry
+layer (hidden states and both caches).   python tools/gemm8p_soak.py [launches per shape] [--no-rope]"""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -62,5 +63,49 @@ for M, K, N in ((2048, 4096, 12288), (2048, 11008, 4096), (4096, 4096, 4096)):
     work = torch.empty(llmie.linear_fp8_workspace_bytes(M, K, N), dtype=torch.uint8, device=dev)
     y = torch.empty((M, N), device=dev, dtype=torch.float16)
     screen("e4m3 plain %dx%dx%d" % (M, N, K), lambda: llmie.linear_fp8(x, wq, ws, y, work), y)
+# ---- round 3: the ROPE forms (QKV projection with RoPE + KV-cache append as its epilogue) through one 7B-geometry engine layer:
+#      hidden states AND the K cache of every repeated prefill must reproduce the first one bit for bit
+if "--no-rope" not in sys.argv:
+    import numpy as np
+    nh, hs, I = 32, 128, 11008
+    H, QKV = nh * hs, 3 * nh * hs
+    mk = lambda n, k: (torch.randn((n, k), device=dev, generator=g) / k ** 0.5).half()
+    raw = dict(qkv=mk(QKV, H), o=mk(H, H), gate_up=mk(2 * I, H), down=mk(H, I))
+    gam = lambda: (torch.rand((H,), device=dev, generator=g) * 0.4 + 0.8).half()
+    for wfmt in ("f16", "int8", "fp8"):
+        def quant(w):
+            n, k = w.shape
+            if wfmt == "f16":
+                return dict(data=w)
+            if wfmt == "int8":
+                q, sc = torch.empty((n, k), dtype=torch.int8, device=dev), torch.empty(n, dtype=torch.float16, device=dev)
+                llmie.quantize_w8(w, q, sc)
+            else:
+                q, sc = torch.empty((n, k), dtype=torch.uint8, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
+                llmie.quantize_fp8(w, q, sc)
+            return dict(data=q, scale=sc)
+        layers = [dict(attn_norm=gam(), ffn_norm=gam(), qkv=quant(raw["qkv"]), o=quant(raw["o"]), gate_up=quant(raw["gate_up"]), down=quant(raw["down"]))]
+        for lens in ([2048], [512] * 8, [700, 300, 1048]):
+            bs, T, max_seq = len(lens), sum(lens), max(lens)
+            cfg = dict(head_num=nh, kv_head_num=nh, head_size=hs, inter_size=I, num_layers=1, vocab_size=100, max_seq_len=max_seq, max_batch=bs,
+                       rotary_dim=hs, rotary_base=10000.0, rms_eps=1e-5, dtype=llmie.F16,
+                       wfmt={"f16": llmie.W_F16, "int8": llmie.W_INT8, "fp8": llmie.W_FP8}[wfmt], int4_group=128)
+            dec = llmie.Decoder(cfg, layers)
+            x = torch.randn((T, H), device=dev, generator=g).half()
+            out = torch.empty_like(x)
+            kc = torch.zeros((1, bs, nh, max_seq, hs), device=dev, dtype=torch.float16)
+            vc = torch.zeros_like(kc)
+            ld = torch.tensor(lens, dtype=torch.int32, device=dev)
+            hd = torch.zeros(bs, dtype=torch.int32, device=dev)
+            both = torch.empty(out.numel() + kc.numel() + vc.numel(), device=dev, dtype=torch.float16)
+
+            def fn():
+                kc.zero_(); vc.zero_()
+                dec.prefill(x, out, kc, vc, ld, hd, max_seq)
+                both[:out.numel()] = out.flatten()
+                both[out.numel():out.numel() + kc.numel()] = kc.flatten()
+                both[out.numel() + kc.numel():] = vc.flatten()
+            screen("prefill %s %s tokens (QKV + RoPE epilogue)" % (wfmt, "x".join(map(str, lens)) if len(set(lens)) > 1 else "%dx%d" % (bs, lens[0])), fn, both)
+            dec.close()
 print("RESULT:", "FAILED" if bad else "all identical")
 sys.exit(1 if bad else 0)
