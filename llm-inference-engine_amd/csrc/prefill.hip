@@ -247,8 +247,10 @@ int prefill_token_table(const int32_t *cum_seqlens, const int32_t *history_len, 
 
 // grid: (q tiles of NW*16 rows over max_q_len, head_num, batch); block = NW waves x 16 query rows.  NW = 8: a staged 64-key K/V
 // tile (global -> LDS, two barriers: 80 of the 175 us of the 4-wave form at 2048 tokens) serves 128 query rows.
-template <int HS, bool KV8, int NW>
-__global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__restrict__ qkv, const void *__restrict__ k_cache,
+// RT = 16-row query tiles per wave (round 3): with RT = 2 every K / V^T fragment a wave reads from LDS feeds two MFMAs, and a
+// 4-wave workgroup covers the same 128 query rows -- two such workgroups share a CU and run out of phase with each other.
+template <int HS, bool KV8, int NW, int RT = 1>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) void prefill_flash_kernel(const half_t *__restrict__ qkv, const void *__restrict__ k_cache,
                                                             const void *__restrict__ v_cache, half_t *__restrict__ out,
                                                             const int32_t *__restrict__ cum, const int32_t *__restrict__ hist,
                                                             int head_num, int kv_head_num, int max_seq_len, size_t layer_off,
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
     // group reads a block of 4 keys x 16 head dims and every lane receives one column of it = 4 consecutive keys of its head
     // dim), whose 16 lanes address 4 rows x 4 eight-byte pieces -- rows 32 bytes apart modulo 256 keep a 32-lane half
     // conflict-free.  (The first version gathered the column with 8 scalar 2-byte LDS reads per fragment: 63 of 175 us.)
-    constexpr int BQ = NW * 16, BT = 64, VSTRIDE = HS + 16, NTHR = NW * 64;
+    constexpr int BQ = NW * 16 * RT, BT = 64, VSTRIDE = HS + 16, NTHR = NW * 64, WROWS = 16 * RT;   // WROWS = query rows per wave
     // two K/V tile buffers (2 x 34 KiB): tile t+1 is written while tile t is multiplied, ONE barrier per iteration; its
     // global loads are issued a full iteration earlier (registers), pinned ahead of the MFMAs with a scheduling barrier --
     // at 2 resident workgroups per CU nothing else hides an L2/HBM round trip
@@ -274,7 +276,11 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
     const int nx = gridDim.x, rows = gridDim.y * gridDim.z;
     const int lin = blockIdx.x + nx * (blockIdx.y + gridDim.y * blockIdx.z);
     const int kx = lin / rows, rowi = lin - kx * rows;
-    const int xq = nx - 1 - kx;
+    // RT = 2 (4-wave workgroups, two resident per CU, all 512 of the 2048-token case at once): workgroups i and i + 256 share a CU,
+    // so the second half of the ids walks the query tiles UPWARDS from the first -- heavy tile nx - 1 - k meets light tile k
+    // (with the plain longest-first order two 32-key-tile workgroups shared the first CUs: 73 us instead of 61)
+    const int nheavy = (nx + 1) / 2;
+    const int xq = (RT == 1 || kx < nheavy) ? nx - 1 - kx : kx - nheavy;
     const int b = rowi / gridDim.y, h = rowi - b * gridDim.y;
     const int len = cum[b + 1] - cum[b], history = hist[b];
     const int q0 = xq * BQ;
@@ -292,23 +298,32 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
     const float k_rem = KV8 ? k_scale / k_p2 : 1.f, v_rem = KV8 ? v_scale / v_p2 : 1.f;
     const float scale = rsqrtf(static_cast<float>(HS)) * k_rem;
 
-    // this lane's query row (clamped for the tail tile; its results are not stored)
-    const int qrow = q0 + wave * 16 + r;
-    const int qrow_c = min(qrow, len - 1);
-    const half_t *qptr = qkv + (static_cast<size_t>(cum[b] + qrow_c) * heads + h) * HS;
-    half8_t qf[4];
+    // this lane's query rows, one per row tile (clamped for the tail tile; their results are not stored)
+    int qrow[RT], qpos[RT];
+    half8_t qf[RT][4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const half8_t *>(qptr + 32 * s + 8 * q);
-    const int qpos = history + qrow_c;  // keys t <= qpos are visible
+    for (int u = 0; u < RT; ++u) {
+        qrow[u] = q0 + wave * WROWS + u * 16 + r;
+        const int qrow_c = min(qrow[u], len - 1);
+        const half_t *qptr = qkv + (static_cast<size_t>(cum[b] + qrow_c) * heads + h) * HS;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[u][s] = *reinterpret_cast<const half8_t *>(qptr + 32 * s + 8 * q);
+        qpos[u] = history + qrow_c;  // keys t <= qpos are visible
+    }
 
     const half_t *kc = static_cast<const half_t *>(k_cache), *vc = static_cast<const half_t *>(v_cache);
     const uint8_t *kc8 = static_cast<const uint8_t *>(k_cache), *vc8 = static_cast<const uint8_t *>(v_cache);
     (void)kc; (void)vc; (void)kc8; (void)vc8;
 
-    floatx4 o[8];  // O^T tiles: rows d = 16*dt + 4q + e, col = this lane's query row
+    floatx4 o[RT][8];  // O^T tiles of row tile u: rows d = 16*dt + 4q + e, col = this lane's query row
+    float m_run[RT], l_run[RT];
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) o[dt] = floatx4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
+    for (int u = 0; u < RT; ++u) {
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) o[u][dt] = floatx4{0.f, 0.f, 0.f, 0.f};
+        m_run[u] = -INFINITY;
+        l_run[u] = 0.f;
+    }
 
     const int t_hi = min(ctx, history + min(q0 + BQ, len));  // keys needed by any row of this q tile
     constexpr int NCH = 1024 / NTHR;  // 16-byte chunks of each tile per thread
@@ -382,105 +397,112 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
         __builtin_amdgcn_sched_barrier(0);  // keep the loads above the compute below
         FLASH_T(tc);
         FLASH_ACC(1, tb, tc);
-        // key tiles entirely in the future of this wave's 16 query rows are skipped by the whole wave (it still takes part in
+        // key tiles entirely in the future of this wave's query rows are skipped by the whole wave (it still takes part in
         // the staging and the barriers above)
-        if (t0 > history + q0 + wave * 16 + 15) continue;
-        // ---- S^T = K . Q^T : 4 key tiles of 16, 4 k-steps over the head dim ----
+        if (t0 > history + q0 + wave * WROWS + WROWS - 1) continue;
+        // ---- S^T = K . Q^T : 4 key tiles of 16, 4 k-steps over the head dim, RT row tiles per fragment ----
         // all 16 K fragments of the tile are read before the first MFMA (the compiler's own order was read -> wait -> MFMA,
         // one LDS round trip per MFMA)
-        half8_t kfr[4][4];
+        // RT = 1: all 16 K fragments of the tile are read before the first MFMA (the compiler's own order was read -> wait -> MFMA, one
+        // LDS round trip per MFMA).  RT = 2: two batches of 8 fragments -- k-steps 0-1, then 2-3, of all four key tiles: the
+        // accumulators stay 4 RT independent chains -- 32 instead of 64 fragment registers beside 64 output and 32 logit accumulators.
+        constexpr int KSB = RT == 1 ? 1 : 2, KSS = 4 / KSB;   // batches, k-steps per batch
+        floatx4 sacc[RT][4];
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            const int row = tt * 16 + r;
-#ifdef FLASH_SKIP_K   // timing experiment only (wrong results): half of the K fragment reads
-            if (tt >= 2) {
+        for (int sb = 0; sb < KSB; ++sb) {
+            half8_t kfr[4][KSS];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) kfr[tt][s] = kfr[tt - 2][s];
-                continue;
+            for (int tt = 0; tt < 4; ++tt) {
+                const int row = tt * 16 + r;
+#pragma unroll
+                for (int s = 0; s < KSS; ++s)
+                    kfr[tt][s] = *reinterpret_cast<const half8_t *>(Ks + row * HS + ((((sb * KSS + s) * 4 + q) ^ (row & 15)) << 3));
             }
-#endif
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) kfr[tt][s] = *reinterpret_cast<const half8_t *>(Ks + row * HS + (((s * 4 + q) ^ (row & 15)) << 3));
+            for (int s = 0; s < KSS; ++s)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int u = 0; u < RT; ++u)   // (first k-step: the zero C operand is an inline constant, no accumulator to clear)
+                        sacc[u][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[tt][s], qf[u][sb * KSS + s],
+                                                                             (sb == 0 && s == 0) ? floatx4{0.f, 0.f, 0.f, 0.f} : sacc[u][tt], 0, 0, 0);
+            if constexpr (KSB > 1) __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        floatx4 sacc[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s)  // 4 independent accumulators per k-step: no back-to-back dependent MFMAs
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt)   // (first k-step: the zero C operand is an inline constant, no accumulator to clear)
-                sacc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[tt][s], qf[s], s == 0 ? floatx4{0.f, 0.f, 0.f, 0.f} : sacc[tt], 0, 0, 0);
-        // lane holds S[qrow][t = t0 + 16 tt + 4 q + e].  Softmax in the log2 domain: s2 = S * scale * log2(e), p = 2^(s2 - m)
-        // (one v_exp_f32 per element, no separate multiply); the causal / length mask is only evaluated on tiles that reach past
-        // the wave's first query position or the context end (wave-uniform test), and 2^(-inf) = 0 needs no select.
 #ifdef FLASH_STAMPS
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        asm volatile("" : "+v"(sacc[0]), "+v"(sacc[1]), "+v"(sacc[2]), "+v"(sacc[3]));
+        asm volatile("" : "+v"(sacc[0][0]), "+v"(sacc[0][1]), "+v"(sacc[0][2]), "+v"(sacc[0][3]));
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // (MFMA results written: the next read of them would wait anyway)
 #endif
         FLASH_T(td);
         FLASH_ACC(2, tc, td);
-        // (VALU diet, round 3: the kernel is bound by VALU ISSUE -- ~330 VALU slots per wave and tile against 32 MFMAs, two waves
-        // per SIMD)  The row maximum is taken over the RAW logits and scaled once (scale2 > 0), the scale rides in
-        // the exponent's FMA, numerators are converted to fp16 in pairs.
+        // lane holds S[qrow[u]][t = t0 + 16 tt + 4 q + e].  Softmax in the log2 domain, p = 2^(S * scale2 - m).  VALU diet (round 3:
+        // the loop issued ~330 VALU slots per wave and tile against 32 MFMAs): the row maximum is taken over the RAW
+        // logits and scaled once (scale2 > 0), the scale rides in the exponent's FMA, numerators are converted to fp16 in pairs;
+        // the causal / length mask is only evaluated on tiles that reach past the wave's first query position or the context end
+        // (wave-uniform test), and 2^(-inf) = 0 needs no select.
         const float scale2 = scale * 1.44269504088896341f;
-        const bool need_mask = t0 + BT - 1 > history + q0 + wave * 16 || t0 + BT > ctx;
-        float mloc = -INFINITY;
-        if (need_mask) {
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int t = t0 + tt * 16 + 4 * q + e;
-                    const float v = (t <= qpos && t < ctx) ? sacc[tt][e] : -INFINITY;
-                    sacc[tt][e] = v;
-                    mloc = fmaxf(mloc, v);
-                }
-        } else {
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) mloc = fmaxf(mloc, sacc[tt][e]);
-        }
-        // maximum over the 4 lanes of a query row (lanes r, r + 16, r + 32, r + 48) with the gfx950 row-swap instructions (VALU:
-        // v_permlane32_swap pairs every lane with the one 32 lanes away, v_permlane16_swap with the one 16 away) instead of two
-        // dependent ds_bpermute round trips through the LDS crossbar, each behind an lgkmcnt(0) that also drains the wave's fragment reads
-        mloc = lane_xor_max<16>(lane_xor_max<32>(mloc));   // (device_utils.cuh)
-        mloc *= scale2;   // (-inf stays -inf)
-        const float m_new = fmaxf(m_run, mloc);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: keep everything at zero
-        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_use);
-        float lsum = 0.f;
-        half8_t pf[2];  // P^T fragments = MFMA B operand of the two 32-key steps
+        const bool need_mask = t0 + BT - 1 > history + q0 + wave * WROWS || t0 + BT > ctx;
+        half8_t pf[RT][2];  // P^T fragments of row tile u = MFMA B operand of the two 32-key steps
         typedef float float2v_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
+        for (int u = 0; u < RT; ++u) {
+            float mloc = -INFINITY;
+            if (need_mask) {
 #pragma unroll
-            for (int e = 0; e < 4; e += 2) {
-                // p = 2^(s * scale2 - m): one FMA + one v_exp_f32 per element (2^(-inf) = 0 for masked keys)
-                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[tt][e], scale2, -m_use));
-                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[tt][e + 1], scale2, -m_use));
-                lsum += p0 + p1;
-                const half2_t h = __builtin_convertvector(float2v_t{p0, p1}, half2_t);   // v_cvt_pk_f16_f32 (round to nearest even)
-                pf[tt >> 1][(tt & 1) * 4 + e] = h[0];
-                pf[tt >> 1][(tt & 1) * 4 + e + 1] = h[1];
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int t = t0 + tt * 16 + 4 * q + e;
+                        const float v = (t <= qpos[u] && t < ctx) ? sacc[u][tt][e] : -INFINITY;
+                        sacc[u][tt][e] = v;
+                        mloc = fmaxf(mloc, v);
+                    }
+            } else {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) mloc = fmaxf(mloc, sacc[u][tt][e]);
             }
-        // l_run is this lane's PARTIAL row sum (its 16 of the tile's 64 keys): alpha is the same for the 4 lanes of a row, so the
-        // cross-lane reduction is linear and done once after the last tile instead of two LDS-path shuffles per tile
-        l_run = l_run * alpha + lsum;
-        m_run = m_new;
-        // the running maximum rarely moves after the first tiles: skip the 32 rescaling multiplies when no row of the wave needs them
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+            // maximum over the 4 lanes of a query row (lanes r, r + 16, r + 32, r + 48) with the gfx950 row-swap instructions (VALU:
+            // v_permlane32_swap pairs every lane with the one 32 lanes away, v_permlane16_swap with the one 16 away) instead of two
+            // dependent ds_bpermute round trips through the LDS crossbar, each behind an lgkmcnt(0) that also drains the wave's reads
+            mloc = lane_xor_max<16>(lane_xor_max<32>(mloc));   // (device_utils.cuh)
+            mloc *= scale2;   // (-inf stays -inf)
+            const float m_new = fmaxf(m_run[u], mloc);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: keep everything at zero
+            const float alpha = (m_run[u] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run[u] - m_use);
+            float lsum = 0.f;
 #pragma unroll
-            for (int dt = 0; dt < 8; ++dt) o[dt] *= alpha;
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    // p = 2^(s * scale2 - m): one FMA + one v_exp_f32 per element (2^(-inf) = 0 for masked keys)
+                    const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[u][tt][e], scale2, -m_use));
+                    const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[u][tt][e + 1], scale2, -m_use));
+                    lsum += p0 + p1;
+                    const half2_t hh = __builtin_convertvector(float2v_t{p0, p1}, half2_t);   // v_cvt_pk_f16_f32 (round to nearest even)
+                    pf[u][tt >> 1][(tt & 1) * 4 + e] = hh[0];
+                    pf[u][tt >> 1][(tt & 1) * 4 + e + 1] = hh[1];
+                }
+            // l_run is this lane's PARTIAL row sum (its 16 of the tile's 64 keys): alpha is the same for the 4 lanes of a row, so
+            // the cross-lane reduction is linear and done once after the last tile
+            l_run[u] = l_run[u] * alpha + lsum;
+            m_run[u] = m_new;
+            // skip the 32 rescaling multiplies when no row of the wave needs them
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) o[u][dt] *= alpha;
+            }
         }
 #ifdef FLASH_STAMPS
-        asm volatile("" : "+v"(pf[0]), "+v"(pf[1]));
+        asm volatile("" : "+v"(pf[0][0]), "+v"(pf[0][1]));
 #endif
         FLASH_T(te);
         FLASH_ACC(3, td, te);
-        // ---- O^T += V^T . P^T : A fragment = V[t(q,j)][d = 16 dt + r] gathered down a column ----
+        // ---- O^T += V^T . P^T : A fragment = V[t(q,j)][d = 16 dt + r] gathered down a column, shared by the RT row tiles ----
         // lane (r, q) of its 16-lane group supplies the address of block row (r >> 2), columns 4 (r & 3) .. +3, and receives
-        // column r of the block's 4 rows; all 16 transposed reads of a 32-key step are issued before its 8 MFMAs
+        // column r of the block's 4 rows; all 16 transposed reads of a 32-key step are issued before its 8 RT MFMAs
         typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
         typedef __attribute__((address_space(3))) fp16x4_t *lds_fp16x4_ptr;
 #pragma unroll
@@ -500,11 +522,12 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
             for (int dt = 0; dt < 8; ++dt) {
                 struct V8 { fp16x4_t lo, hi; };   // the two transposed reads side by side ARE the 8-half A operand: no repacking
                 const half8_t vf = __builtin_bit_cast(half8_t, V8{lo[dt], hi[dt]});
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[c], o[dt], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < RT; ++u) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[u][c], o[u][dt], 0, 0, 0);
             }
         }
 #ifdef FLASH_STAMPS
-        asm volatile("" : "+v"(o[0]), "+v"(o[7]));
+        asm volatile("" : "+v"(o[0][0]), "+v"(o[0][7]));
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
 #endif
         FLASH_T(tf);
@@ -516,16 +539,18 @@ __global__ __launch_bounds__(NW * 64) void prefill_flash_kernel(const half_t *__
         for (int i = 0; i < 8; ++i) flash_stamp_buf[(lin * 8 + wave) * 8 + i] = stamp_acc[i];
     }
 #endif
-    l_run = lane_xor_sum<16>(l_run);
-    l_run = lane_xor_sum<32>(l_run);
-    if (qrow < len) {
-        const float inv = v_rem / (l_run + 1e-6f);  // the reference's denominator epsilon (scale_and_mask_and_softmax.cu:118)
-        half_t *optr = out + (static_cast<size_t>(cum[b] + qrow) * head_num + h) * HS;
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
-            const half4_t v = {from_f32<half_t>(o[dt][0] * inv), from_f32<half_t>(o[dt][1] * inv),
-                               from_f32<half_t>(o[dt][2] * inv), from_f32<half_t>(o[dt][3] * inv)};
-            *reinterpret_cast<half4_t *>(optr + dt * 16 + 4 * q) = v;
+    for (int u = 0; u < RT; ++u) {
+        const float l = lane_xor_sum<32>(lane_xor_sum<16>(l_run[u]));
+        if (qrow[u] < len) {
+            const float inv = v_rem / (l + 1e-6f);  // the reference's denominator epsilon (scale_and_mask_and_softmax.cu:118)
+            half_t *optr = out + (static_cast<size_t>(cum[b] + qrow[u]) * head_num + h) * HS;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                const half4_t v = {from_f32<half_t>(o[u][dt][0] * inv), from_f32<half_t>(o[u][dt][1] * inv),
+                                   from_f32<half_t>(o[u][dt][2] * inv), from_f32<half_t>(o[u][dt][3] * inv)};
+                *reinterpret_cast<half4_t *>(optr + dt * 16 + 4 * q) = v;
+            }
         }
     }
 }
@@ -541,8 +566,15 @@ int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, void *k_cache, vo
     }
     const size_t layer_off = block_table ? static_cast<size_t>(layer) * num_pages * kv_head_num * 128 * head_size
                                          : static_cast<size_t>(layer) * batch * kv_head_num * max_seq_len * head_size;
-    constexpr int nw = 8;  // waves per workgroup (x 16 query rows)
-    const int bq = nw * 16;
+    // 128 query rows per workgroup either way: 8 waves x 16 rows (one workgroup per CU at a time, dynamic rounds, longest first), or
+    // 4 waves x 2 x 16 rows (every fragment read from LDS feeds two MFMAs; two workgroups per CU, out of phase with each other).
+    // Measured (bench, same box, us per layer): 8 x 512 tokens 54.5 -> 47.5 and 16 x 256 tokens 38 with the 4-wave form; 1 x 2048
+    // 61 -> 70 -- there all 512 workgroups are resident at once, a CU's pair is one long and one short workgroup and the long one
+    // runs most of its tiles alone at one wave per SIMD; 4 x 1024 72 = 72, 2 x 1024 38 -> 41.  Rule: the 4-wave form up to
+    // kFlashRt2MaxQ query rows per sequence.
+    constexpr int kFlashRt2MaxQ = 512;
+    const bool rt2 = max_q_len <= kFlashRt2MaxQ;
+    const int bq = 128;
     dim3 grid((max_q_len + bq - 1) / bq, head_num, batch);
     const float ks = kv_fp8 ? k_scale : 1.f, vs = kv_fp8 ? v_scale : 1.f;
     if (rope_done) {   // the QKV projection's epilogue rotated q in `qkv` and wrote k / v into the caches
@@ -554,11 +586,13 @@ int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, void *k_cache, vo
         prefill_rope_append_kernel<128, false><<<num_tokens, 256, 0, st>>>(qkv, qkv_bias, k_cache, v_cache, cum_seqlens, history_len,
                                                                            rope, batch, head_num, kv_head_num, max_seq_len,
                                                                            rotary_dim, layer_off, 1.f, 1.f, block_table, max_pages);
-#define LLMIE_FLASH(KV8_, NW_)                                                                                                  \
-    prefill_flash_kernel<128, KV8_, NW_><<<grid, NW_ * 64, 0, st>>>(qkv, k_cache, v_cache, out, cum_seqlens, history_len, head_num, \
-                                                                    kv_head_num, max_seq_len, layer_off, ks, vs, block_table, max_pages)
-    if (kv_fp8) LLMIE_FLASH(true, 8);
-    else LLMIE_FLASH(false, 8);
+#define LLMIE_FLASH(KV8_, NW_, RT_)                                                                                                      \
+    prefill_flash_kernel<128, KV8_, NW_, RT_><<<grid, NW_ * 64, 0, st>>>(qkv, k_cache, v_cache, out, cum_seqlens, history_len, head_num, \
+                                                                         kv_head_num, max_seq_len, layer_off, ks, vs, block_table, max_pages)
+    if (kv_fp8 && rt2) LLMIE_FLASH(true, 4, 2);
+    else if (kv_fp8) LLMIE_FLASH(true, 8, 1);
+    else if (rt2) LLMIE_FLASH(false, 4, 2);
+    else LLMIE_FLASH(false, 8, 1);
 #undef LLMIE_FLASH
     return launch_status("prefill_attention");
 }
