@@ -882,6 +882,22 @@ extern "C" int llmie_decoder_forward_paged(llmie_decoder *dec, const void *hidde
     return rc;
 }
 
+// slabs of a prefill pass: the engine format's plans up to 192 rows, and -- for projections whose 256-row grid does not fill the chip
+// at T rows, which fp16 engines and the fp16 weight images of int4 / packed-only engines may run as 128-row split-K passes
+// (linear_f16_nk's time model) -- the fp16 plans at 128 rows
+static size_t prefill_slab_floats(const llmie_decoder_config *c, int T) {
+    size_t m = engine_slab_floats(c, T < 192 ? T : 192);
+    if (T > 192 && c->wfmt != LLMIE_W_FP8) {
+        const int H = c->head_num * c->head_size, QKV = (c->head_num + 2 * c->kv_head_num) * c->head_size, I = c->inter_size;
+        const int shapes[4][2] = {{H, QKV}, {H, H}, {H, 2 * I}, {I, H}};
+        for (const auto &sh : shapes) {
+            if (gemm256_fills(T, sh[1])) continue;
+            const size_t f = linear_splitk_ws_floats(16, 128, sh[0], sh[1]);
+            m = f > m ? f : m;
+        }
+    }
+    return m;
+}
 static size_t prefill_carve(const llmie_decoder_config *c, int T, int B, size_t *o /*[11]*/) {
     const size_t e = 2, H = static_cast<size_t>(c->head_num) * c->head_size;
     const size_t QKV = static_cast<size_t>(c->head_num + 2 * c->kv_head_num) * c->head_size, I = c->inter_size;
@@ -895,7 +911,7 @@ static size_t prefill_carve(const llmie_decoder_config *c, int T, int B, size_t 
     o[6] = k.take(static_cast<size_t>(B + 1) * sizeof(int32_t));    // cum_seqlens
     // fp8 engines: per-token e4m3 image + scales of the activation matrix entering each projection
     o[7] = k.take(c->wfmt == LLMIE_W_FP8 ? llmie_linear_fp8_workspace_bytes(T, static_cast<int>(I > H ? I : H), 0) : 256);
-    o[8] = k.take(engine_slab_floats(c, T < 192 ? T : 192) * sizeof(float) + 256);   // split-K slabs (short prefills; fp8 passes)
+    o[8] = k.take(prefill_slab_floats(c, T) * sizeof(float) + 256);   // split-K slabs (short prefills; fp8 passes; mid-size fp16 passes)
     // int8 / int4 engines at prefill-sized T: room for the fp16 image of the largest matrix (projections without an in-kernel
     // de-quantising form: int4, and int8 shapes whose 256-row grid does not fill the chip)
     size_t dq = 0;
@@ -957,7 +973,7 @@ extern "C" int llmie_decoder_prefill(llmie_decoder *dec, const void *hidden_in, 
     half_t *h = (half_t *)hidden_out;
     void *f8ws = base + o[7];
     const size_t f8ws_bytes = fp8 ? llmie_linear_fp8_workspace_bytes(T, I > H ? I : H, 0) : 0;
-    const SlabWs slabs{reinterpret_cast<float *>(base + o[8]), engine_slab_floats(&c, T < 192 ? T : 192)};
+    const SlabWs slabs{reinterpret_cast<float *>(base + o[8]), prefill_slab_floats(&c, T)};
     void *deq = base + o[9];
     const size_t deq_bytes = o[10] - o[9];
     QkvRopeArgs *rope_args = (QkvRopeArgs *)(base + o[10]);   // (device copy of the fused QKV epilogue's operands)

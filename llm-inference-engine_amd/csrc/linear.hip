@@ -809,9 +809,10 @@ void gemm256_launch(bool fp8, const void *x, const void *W, half_t *y, int M, in
     const float narrow = 0.6f;
     float best = static_cast<float>(rounds(tiles4));
     int plan = 4;
-    if (gemm256_wn(M, N) == 2) {  // the 256-wide grid does not fill the chip (unchanged rule)
+    if (gemm256_wn(M, N) != 4 && (N % 4 != 0 || tiles4 < cus / 2)) {  // the 256-wide grid fills less than half the chip
         plan = 2;
-    } else if (!no_split && N % 4 == 0) {
+    } else if (!no_split && N % 4 == 0) {   // (from half the chip on, the rounds decide: 768 x 12288 is ONE round of 144 wide tiles or
+                                            //  TWO of 288 narrow ones -- 97 against 119 us)
         if (rounds(tiles2) * narrow < best) {
             best = rounds(tiles2) * narrow;
             plan = 2;
@@ -884,7 +885,7 @@ void gemm256_qkv_rope_launch(int kind, const void *x, const void *W, half_t *qkv
     // candidates: all 128-wide; all 256-wide (N a multiple of 256); whole rounds 256-wide + the rest 128-wide
     int plan = 2, a_tn = 0;
     float best = rounds(tm * tn2) * narrow;
-    if (gemm256_wn(M, N) != 2) {
+    if (gemm256_wn(M, N) == 4 || tm * tn4 >= cus / 2) {   // (from half the chip on, the rounds decide: gemm256_launch's rule)
         if (N % 256 == 0 && static_cast<float>(rounds(tm * tn4)) < best) {
             best = static_cast<float>(rounds(tm * tn4));
             plan = 4;
@@ -936,8 +937,25 @@ int linear_f16_nk(const half_t *x, const half_t *W, half_t *y, int M, int K, int
         const GemvArgs a{x, W, y, K, N, bias, residual, nullptr, nullptr, 0.f, epi, 0, nullptr, 0};
         done = dispatch_gemv(M, a, st);
     }
-    // decode / short-prefill batches: split-K over the caller's slabs (without a workspace: the non-split kernels below)
-    if (!done && ws.p && aligned && M <= 192 && K % 128 == 0 && K >= 512)
+    // decode / short-prefill batches: split-K over the caller's slabs (without a workspace: the non-split kernels below).
+    // Round 3, 192 < M where the eight-phase kernels' 256-row grid does not fill the chip (N = 4096 at 256-1023 tokens): such
+    // shapes used to fall to the 128 x 128 kernel -- 82 us for the O and 190 us for the down projection of a 7B layer WHATEVER the
+    // row count.  Two cheaper forms, picked by a two-term time model fitted to the measurements (tools/dev/s2_run18.sh sweep):
+    //   split-K passes of 128 rows:  passes x (weight bytes / 4.2 TB/s + 10 us)          O: 19.5 us per pass, down: 30 us
+    //   256 x 128 eight-phase tiles: rounds of 256 tiles x K / 64 k-tiles x 0.9 us        O: 58 us, down: 140 us per round
+    bool mid_rows = false, mid_tiles = false;
+    if (M > 192 && epi != EPI_SWIGLU && aligned && K % 64 == 0 && !gemm256_fills(M, N)) {
+        const int passes = (M + kSplitKPassRows - 1) / kSplitKPassRows;
+        const float t_split = passes * (static_cast<float>(N) * K * 2.f / 4.2e6f + 10.f);
+        const int tiles2 = ((M + 255) / 256) * ((N + 127) / 128);
+        const float t_tiles = static_cast<float>((tiles2 + 255) / 256) * (K / 64) * 0.9f;
+        const bool split_ok = ws.p && K % 128 == 0 && K >= 512 && ws.floats >= linear_splitk_ws_floats(16, kSplitKPassRows, K, N);
+        const bool tiles_ok = g8p_fits(N, K, false) && reinterpret_cast<uintptr_t>(y) % 8 == 0 &&
+                              (reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) % 8 == 0;
+        mid_rows = split_ok && (!tiles_ok || t_split < t_tiles);
+        mid_tiles = tiles_ok && !mid_rows;
+    }
+    if (!done && ws.p && aligned && (M <= 192 || mid_rows) && K % 128 == 0 && K >= 512)
         return linear_splitk(16, x, W, nullptr, y, M, K, N, epi, bias, residual, ws, st);
     if (!done && aligned && M <= 64 && K % 32 == 0 && (epi != EPI_SWIGLU || (N / 2) % 16 == 0)) {
         done = (epi == EPI_SWIGLU) ? dispatch_skinny<EPI_SWIGLU>(M, x, W, y, K, N, bias, residual, st)
@@ -953,7 +971,7 @@ int linear_f16_nk(const half_t *x, const half_t *W, half_t *y, int M, int K, int
     }
     if (!done && aligned && K % 64 == 0 && reinterpret_cast<uintptr_t>(y) % 8 == 0) {
         // 256 x 256 LDS-DMA kernel when its grid fills the chip (one 512-thread workgroup per CU); else 128 x 128 tiles
-        if (gemm256_fills(M, N) && (reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) % 8 == 0) {
+        if ((gemm256_fills(M, N) || mid_tiles) && (reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) % 8 == 0) {
             gemm256_launch(false, x, W, y, M, N, K, bias, residual, nullptr, nullptr, st);
             return launch_status("linear(gemm256)");
         }
@@ -983,7 +1001,9 @@ extern "C" size_t llmie_linear_workspace_bytes(llmie_weight_format fmt, int M, i
         case LLMIE_W_FP8: wbits = WF_FP8; break;
         default: return 0;
     }
-    if (fmt == LLMIE_W_F16 && M > 192) return 0;   // prefill-sized fp16: tiled kernels, no slabs
+    // prefill-sized fp16: tiled kernels, no slabs -- except where the 256-row grid does not fill the chip: split-K passes of 128
+    // rows may be the cheaper form there (linear_f16_nk's time model)
+    if (fmt == LLMIE_W_F16 && M > 192 && gemm256_fills(M, N)) return 0;
     // int8 / int4 at prefill-sized M: room for the fp16 image of W in front of the slabs (llmie_linear_w8a16 / _w4a16)
     const size_t dq = (fmt == LLMIE_W_INT8 || fmt == LLMIE_W_INT4) ? ((linear_wq_dequant_bytes(wbits, M, K, N) + 255) & ~static_cast<size_t>(255)) : 0;
     return dq + linear_splitk_ws_floats(wbits, M, K, N) * sizeof(float);

@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+timeout -k 10 1100 python -m pytest tests/test_kernels_gpu.py tests/test_prefill_gpu.py tests/test_quant_gpu.py -x -q > gpurun_out/s2_t20.log 2>&1; rc=$?; echo "rc=$rc" >> gpurun_out/s2_t20.log
+tail -3 gpurun_out/s2_t20.log | cut -c1-600
+[ $rc -ne 0 ] && exit 1
+for T in 640 768 896; do timeout -k 10 200 python3 bench.py --only prefill:f16:1:$T 2>/dev/null | tail -1 | cut -c1-330; done
+for T in 256 384 512 768 1024; do timeout -k 10 200 python3 bench.py --only prefill:int8:1:$T 2>/dev/null | tail -1 | cut -c1-330; done
