@@ -120,13 +120,15 @@ struct Carve {
 // Largest decode batch on the GEMV path.  Its dot products are VALU work that grows with the batch while a packed-weight
 // (MFMA) step is nearly flat, so the switch sits at the measured crossover (MI355X, 7B, ctx 512, tokens/s GEMV vs packed,
 // round 2): fp16 b3 924 / 905, b4 1140 / 1186; int8 b2 918 / 828, b3 1172 / 1211; fp8 b2 804 / 720, b3 1009 / 1044;
-// int4 (ctx 2048) b1 460 / 442, b2 710 / 812.
+// int4 (ctx 2048) b1 460 / 442, b2 710 / 812.  Re-measured at the end of round 3 (the GEMV had gained ~10 % since: four rows per
+// iteration, two rows per instruction for int4): fp16 b4 1302 / 1203, b5 1516 / 1452, b6 1710 / 1731; int8 b3 1240 / 1244, b4 1477 /
+// 1637; fp8 b3 1036 / 1171; int4 (ctx 512) b2 1012 / 939.
 static int gemv_max_batch(llmie_weight_format wfmt) {
     switch (wfmt) {
-        case LLMIE_W_F16: return 3;
+        case LLMIE_W_F16: return 5;
         case LLMIE_W_INT8: return 2;
         case LLMIE_W_FP8: return 2;
-        case LLMIE_W_INT4: return 1;
+        case LLMIE_W_INT4: return 2;
         default: return 4;
     }
 }
