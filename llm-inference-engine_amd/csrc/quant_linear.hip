@@ -189,7 +189,18 @@ int linear_wq(int wbits, const half_t *x, const void *wq, const half_t *scale, h
                            reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(pre_bias)) % 16 == 0) &&
                          (static_cast<size_t>(K) * wbits / 8) % 16 == 0;
     // ---- prefill-sized row counts: MFMA-bound, the weights are read M / 256 times from L2 instead of streamed once ----
-    if (M >= kWqPrefillRows && !gamma) {
+    // (round 3) int8, M from 192, shapes whose 256-row grid does not fill the chip (N = 4096 of a 7B layer at 193 .. 1023 tokens):
+    // split-K passes of 128 rows on the int8 rows against the fp16 image + a partly filled tile grid, by a time model fitted to the
+    // sweep (us; O / down of a 7B layer: 22 / 33 per pass against 56 / 123 for the image route whatever the row count):
+    //   passes x (N K bytes / 2.8 TB/s + 16)   <   N K x 3 bytes / 4 TB/s  +  K / 64 x 0.55
+    bool int8_mid_passes = false;
+    if (wbits == 8 && M >= kWqPrefillRows && !gamma && epi == EPI_NONE && ws.p && aligned && K % 256 == 0 && K >= 512 &&
+        !g8p_w8_eligible(M, K, N, x, wq, scale, y) && ws.floats >= linear_splitk_ws_floats(8, 128, K, N)) {
+        const float nk = static_cast<float>(N) * K;
+        const float t_passes = ((M + 127) / 128) * (nk / 2.8e6f + 16.f), t_image = nk * 3.f / 4.0e6f + (K / 64) * 0.55f;
+        int8_mid_passes = t_passes * 1.05f < t_image;   // (ties go to the image route)
+    }
+    if (M >= kWqPrefillRows && !gamma && !int8_mid_passes) {
         // int8: the eight-phase GEMM takes the int8 rows as they are (raw bytes HBM -> LDS by DMA, de-quantised at fragment read,
         // scale in the epilogue)
         if (wbits == 8 && epi == EPI_SWIGLU && !bias && !residual && g8p_w8_swiglu_eligible(M, K, N, x, wq, scale, y)) {
