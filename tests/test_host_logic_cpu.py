@@ -13,8 +13,12 @@ def lib(llmie):
 def test_linear_workspace_query_follows_the_split_k_plans(llmie, lib):
     F16, I8, I4, FP8 = llmie.W_F16, llmie.W_INT8, llmie.W_INT4, llmie.W_FP8
     q = lib.llmie_linear_workspace_bytes
-    # fp16: decode and short-prefill batches only (above 192 rows the tiled kernels need no slabs)
-    assert q(F16, 1, 4096, 4096) > 0 and q(F16, 192, 4096, 4096) > 0 and q(F16, 193, 4096, 4096) == 0
+    # fp16: decode and short-prefill batches, and (round 3) prefill-sized row counts whose 256-row grid does not fill the chip --
+    # those may run as 128-row split-K passes (N = 4096: up to 768 rows; N = 12288 fills from 257 rows); where the grid fills, the
+    # tiled kernels need no slabs
+    assert q(F16, 1, 4096, 4096) > 0 and q(F16, 192, 4096, 4096) > 0
+    assert q(F16, 193, 4096, 4096) == q(F16, 128, 4096, 4096) and q(F16, 768, 4096, 4096) == q(F16, 128, 4096, 4096)
+    assert q(F16, 1024, 4096, 4096) == 0 and q(F16, 2048, 4096, 12288) == 0 and q(F16, 512, 4096, 12288) == 0
     # shapes without a split-K form: K too short / not a multiple of the sub-block
     assert q(F16, 32, 256, 4096) == 0 and q(F16, 32, 4096 + 64, 4096) == 0 and q(I8, 32, 4096 + 128, 4096) == 0
     # at least one slab of M x N floats, at most 16 slabs; more rows never need less
@@ -76,15 +80,16 @@ def _cfg(llmie, **kw):
 def test_decoder_workspace_grows_with_what_it_has_to_hold(llmie, lib):
     q = lambda **kw: lib.llmie_decoder_workspace_bytes(C.byref(_cfg(llmie, **kw)))
     layer_bytes = (3 * 4096 * 4096 + 4096 * 4096 + 3 * 4096 * 11008) * 2
-    b1, b3, b4, b32, b128 = q(max_batch=1), q(max_batch=3), q(max_batch=4), q(max_batch=32), q(max_batch=128)
-    assert 0 < b1 <= b3 < b4 <= b32 < b128
-    # fp16 engines above the GEMV range (3 rows) carry the packed second copy of the layer weights
-    assert b4 - b3 >= 2 * layer_bytes and b3 < layer_bytes
-    # int8: from batch 3; int4: from batch 2, with its group-scale images
+    b1, b5, b6, b32, b128 = q(max_batch=1), q(max_batch=5), q(max_batch=6), q(max_batch=32), q(max_batch=128)
+    assert 0 < b1 <= b5 < b6 <= b32 < b128
+    # fp16 engines above the GEMV range (5 rows since the crossover was re-measured at the end of round 3) carry the packed second
+    # copy of the layer weights
+    assert b6 - b5 >= 2 * layer_bytes and b5 < layer_bytes
+    # int8: from batch 3; int4: from batch 3 as well (its batch 2 went back to the GEMV), with its group-scale images
     i8 = lambda b: q(max_batch=b, wfmt=llmie.W_INT8)
     assert i8(3) - i8(2) >= layer_bytes
     i4 = lambda b: q(max_batch=b, wfmt=llmie.W_INT4)
-    assert i4(2) - i4(1) >= layer_bytes // 2
+    assert i4(3) - i4(2) >= layer_bytes // 2
     # the split-K slab area covers the LM head too (a 32000-row vocabulary beside small layers: its slabs dominate)
     small = dict(head_num=8, kv_head_num=8, head_size=64, inter_size=768, max_batch=128)
     lm = lib.llmie_linear_workspace_bytes(llmie.W_F16, 128, 512, 32000)
