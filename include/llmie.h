@@ -335,7 +335,7 @@ typedef struct {
     int flags;
 } llmie_decoder_config;
 
-/* Weight residency (ABI 3).  An engine whose max_batch lies above the GEMV range (fp16 3, int8 / fp8 2, int4 1 rows) builds
+/* Weight residency (ABI 3).  An engine whose max_batch lies above the GEMV range (fp16 5, int8 / fp8 2, int4 2 rows) builds
  * tile-packed images of its four matrices per layer inside its workspace at create time -- a SNAPSHOT: weights updated in place
  * afterwards are seen by the batch <= GEMV-range and prefill paths, not by the packed one; create synchronises the device before
  * it packs, so uploads on any stream have landed.  By default that image is a second copy next to the caller's row-major matrices.
