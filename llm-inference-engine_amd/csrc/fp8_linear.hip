@@ -120,8 +120,18 @@ extern "C" int llmie_quantize_fp8(const void *w, uint8_t *wq, float *scale, int 
 
 namespace llmie {
 static bool fp8_tiled(const void *w_scale, const void *bias, const void *residual, int M, int K, int N) {
-    return M > 8 && gemm256_fills(M, N) && K % 128 == 0 && N % 4 == 0 && reinterpret_cast<uintptr_t>(w_scale) % 16 == 0 &&
-           (reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) % 8 == 0;
+    if (!(M > 8 && K % 128 == 0 && N % 4 == 0 && reinterpret_cast<uintptr_t>(w_scale) % 16 == 0 &&
+          (reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) % 8 == 0))
+        return false;
+    if (gemm256_fills(M, N)) return true;
+    // (round 3) a grid that does not fill the chip against split-K passes of 128 rows, by the time model fitted to the sweep
+    // (tools/dev/s2_run27.sh; us): O / down of a 7B layer 41 / 90 tiled at any row count, 18.9 / 22.3 per pass -- at 768 tokens
+    // the six passes took 113 / 134 us
+    if (M <= 128 || static_cast<size_t>(N + 512) * K >= (size_t{1} << 32)) return false;
+    const int tiles2 = ((M + 255) / 256) * ((N + 127) / 128);
+    const float t_tiles = static_cast<float>((tiles2 + 255) / 256) * (K / 128) * 1.15f;
+    const float t_passes = ((M + 127) / 128) * (static_cast<float>(N) * K / 8.3e6f + 17.f);
+    return t_tiles < t_passes;
 }
 // llmie_linear_fp8 with its two scratch areas apart: `act_ws` (>= llmie_linear_fp8_workspace_bytes(M, K, 0), 256-byte aligned)
 // receives the quantised activations, `slabs` the split-K partial sums (engine: one slab area serves every projection)
