@@ -30,6 +30,17 @@ def test_every_declared_symbol_is_exported(lib, llmie):
     assert sorted(llmie.EXPORTS) == names
 
 
+def test_integration_notes_name_every_entry():
+    """INTEGRATION.md maps each exported entry to the reference interface it stands for (whole names, in code spans or code blocks)."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    named = set(re.findall(r"\bllmie_[a-z0-9_]+", doc))
+    # `llmie_linear_w8a16/w4a16/fp8`-style shorthands in the launcher table count for their expansions
+    for m in re.finditer(r"\b(llmie_[a-z0-9]+_)([a-z0-9]+(?:/[a-z0-9_]+)+)", doc):
+        named.update(m.group(1) + tail for tail in m.group(2).split("/"))
+    missing = [n for n in _declared() if n not in named]
+    assert not missing, "INTEGRATION.md does not mention: %s" % ", ".join(missing)
+
+
 def test_version_and_arch(lib, llmie):
     assert lib.llmie_abi_version() == 3 == llmie.ABI_VERSION
     assert "#define LLMIE_ABI_VERSION 3" in open(os.path.join(ROOT, "include", "llmie.h")).read()
