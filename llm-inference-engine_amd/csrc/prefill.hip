@@ -574,7 +574,10 @@ int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, void *k_cache, vo
     // kFlashRt2MaxQ query rows per sequence.
     constexpr int kFlashRt2MaxQ = 512;
     const bool rt2 = max_q_len <= kFlashRt2MaxQ;
-    const int bq = 128;
+    // Fewer 128-row workgroups than CUs (one short prompt): 4 waves x 16 rows = 64 query rows per workgroup, twice the workgroups
+    // (interleaved A/B, 7B, one sequence: 128 tokens 27.8k -> 28.1k tok/s, 256 32.6k -> 32.9k, 512 46.0k -> 46.6k, 768 equal)
+    const bool bq64 = ((max_q_len + 127) / 128) * head_num * batch < 256;
+    const int bq = bq64 ? 64 : 128;
     dim3 grid((max_q_len + bq - 1) / bq, head_num, batch);
     const float ks = kv_fp8 ? k_scale : 1.f, vs = kv_fp8 ? v_scale : 1.f;
     if (rope_done) {   // the QKV projection's epilogue rotated q in `qkv` and wrote k / v into the caches
@@ -589,7 +592,9 @@ int prefill_attention_f16(half_t *qkv, const half_t *qkv_bias, void *k_cache, vo
 #define LLMIE_FLASH(KV8_, NW_, RT_)                                                                                                      \
     prefill_flash_kernel<128, KV8_, NW_, RT_><<<grid, NW_ * 64, 0, st>>>(qkv, k_cache, v_cache, out, cum_seqlens, history_len, head_num, \
                                                                          kv_head_num, max_seq_len, layer_off, ks, vs, block_table, max_pages)
-    if (kv_fp8 && rt2) LLMIE_FLASH(true, 4, 2);
+    if (kv_fp8 && bq64) LLMIE_FLASH(true, 4, 1);
+    else if (bq64) LLMIE_FLASH(false, 4, 1);
+    else if (kv_fp8 && rt2) LLMIE_FLASH(true, 4, 2);
     else if (kv_fp8) LLMIE_FLASH(true, 8, 1);
     else if (rt2) LLMIE_FLASH(false, 4, 2);
     else LLMIE_FLASH(false, 8, 1);
