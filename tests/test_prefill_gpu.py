@@ -44,13 +44,18 @@ def oracle_prefill(layers, x, kc, vc, lens, hist, nh, kvh, hs, I, max_seq):
 
 
 CASES = [("single_40", 8, 8, 1376, 2, [40], [0]), ("ragged_hist", 8, 8, 1376, 2, [70, 5, 33], [0, 10, 64]),
-         ("gqa", 8, 2, 1024, 1, [17, 64], [3, 0]), ("long_300_bias", 8, 8, 512, 1, [300], [20])]
+         ("gqa", 8, 2, 1024, 1, [17, 64], [3, 0]), ("long_300_bias", 8, 8, 512, 1, [300], [20]),
+         # the three forms of the flash kernel (prefill_attention_f16 picks by grid and by the longest sequence): the cases above have
+         # fewer 128-row query tiles than the chip has CUs -> 64 query rows per workgroup; 2 tiles x 16 heads x 8 sequences = 256 and
+         # <= 512 rows per sequence -> 4 waves x 2 x 16 rows; > 512 rows -> 8 waves x 16 rows
+         ("rt2_ragged_gqa", 16, 4, 512, 1, [256, 130, 200, 256, 129, 20, 255, 140], [0, 7, 0, 64, 0, 3, 100, 0]),
+         ("w8_long_1100_600", 16, 16, 512, 1, [1100, 600], [20, 0])]
 
 
 @pytest.mark.parametrize("name,nh,kvh,I,L,lens,hist", CASES, ids=[c[0] for c in CASES])
 def test_prefill_matches_oracle(llmie, name, nh, kvh, I, L, lens, hist):
     rng = np.random.default_rng(41)
-    hs, max_seq = 128, 384
+    hs, max_seq = 128, max(384, -(-max(h + l for h, l in zip(hist, lens)) // 128) * 128)
     H, bs, T = nh * hs, len(lens), int(sum(lens))
     layers = _model(rng, nh, kvh, hs, I, L, o_bias="bias" in name)
     dec = _engine(llmie, layers, nh, kvh, hs, I, max_seq, bs)
@@ -130,7 +135,7 @@ def test_quantised_prefill_matches_oracle_on_dequantised_weights(llmie, fmt, nam
     on the DE-QUANTISED weights -- the error left is the fp16 pipeline's, held to the fp16 prefill bounds (<= 64 / 128 tokens: fused
     split-K form; up to 191: split-K passes; from 192: the prefill-sized forms of linear_wq)"""
     rng = np.random.default_rng(43)
-    hs, max_seq = 128, 384
+    hs, max_seq = 128, max(384, -(-max(h + l for h, l in zip(hist, lens)) // 128) * 128)
     H, bs, T = nh * hs, len(lens), int(sum(lens))
     if fmt == "int4":
         I = I // 128 * 128   # group-128 scales along K: the down projection's K = I is a whole number of groups
