@@ -144,3 +144,48 @@ def test_prefill_and_decode_agree_on_fp8_kv_cache(llmie, KS, VS):
     assert ((deq - k3[0].float()).abs() <= 0.07 * k3[0].float().abs() + 1e-2).float().mean().item() > 0.999
     d8.close()
     d16.close()
+
+
+# the three forms of the flash prefill kernel on an e4m3 cache (prefill_attention_f16 picks by grid and by the longest sequence, see
+# tests/test_prefill_gpu.py CASES): 64 query rows per workgroup, 4 waves x 2 x 16 rows, 8 waves x 16 rows
+FORMS = [("bq64_np2", 8, 8, [150, 60], [30, 0], KS_NP2, VS_NP2),
+         ("rt2_ragged_gqa", 16, 4, [256, 130, 200, 256, 129, 20, 255, 140], [0, 7, 0, 64, 0, 3, 100, 0], KS, VS),
+         ("w8_long_np2", 16, 16, [1100, 600], [20, 0], KS_NP2, VS_NP2)]
+
+
+@pytest.mark.parametrize("name,nh,kvh,lens,hist,ks,vs", FORMS, ids=[f[0] for f in FORMS])
+def test_fp8_kv_prefill_tracks_fp16_kv_on_every_flash_form(llmie, name, nh, kvh, lens, hist, ks, vs):
+    """Ragged prefills WITH history rows on an e4m3 cache against the same engine on an fp16 cache holding the de-quantised history
+    (that path is held to the oracle by tests/test_prefill_gpu.py): the outputs differ by the e4m3 rounding of the new rows only,
+    history bytes stay as they were, new rows are e4m3(k / scale)."""
+    rng = np.random.default_rng(64)
+    hs, I, L = 128, 512, 1
+    max_seq = -(-max(h + l for h, l in zip(hist, lens)) // 128) * 128
+    bs, T, H = len(lens), int(sum(lens)), nh * hs
+    layers = _layers(rng, nh, kvh, hs, I, L)
+    d8 = _engine(llmie, layers, nh, kvh, hs, I, max_seq, bs, llmie.KV_FP8, ks, vs)
+    d16 = _engine(llmie, layers, nh, kvh, hs, I, max_seq, bs, llmie.KV_NATIVE)
+    shape = (L, bs, kvh, max_seq, hs)
+    codes = lambda: (rng.integers(0, 0x58, shape).astype(np.uint8) | (rng.integers(0, 2, shape).astype(np.uint8) << 7))
+    ck, cv = codes(), codes()
+    k8, v8 = torch.from_numpy(ck).to(DEV), torch.from_numpy(cv).to(DEV)
+    k16, v16 = torch.from_numpy(TAB[ck] * np.float32(ks)).to(DEV).to(F16), torch.from_numpy(TAB[cv] * np.float32(vs)).to(DEV).to(F16)
+    xs = torch.from_numpy(_h(rng.standard_normal((T, H)).astype(np.float32))).to(DEV).to(F16)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)
+    out8 = d8.prefill(xs, torch.empty_like(xs), k8, v8, i32(lens), i32(hist), max(lens)).float()
+    out16 = d16.prefill(xs, torch.empty_like(xs), k16, v16, i32(lens), i32(hist), max(lens)).float()
+    assert torch.isfinite(out8).all()
+    rel = ((out8 - out16).norm() / out16.norm()).item()
+    print("%s: fp8-KV prefill vs fp16-KV prefill rel %.4f" % (name, rel))
+    assert rel < 0.05, rel
+    tab = torch.from_numpy(TAB).to(DEV)
+    for b, (n, h0) in enumerate(zip(lens, hist)):
+        # rows outside [history, history + len) keep their bytes
+        assert torch.equal(k8[0, b, :, :h0].cpu(), torch.from_numpy(ck[0, b, :, :h0]))
+        assert torch.equal(v8[0, b, :, h0 + n:].cpu(), torch.from_numpy(cv[0, b, :, h0 + n:]))
+        # appended rows: e4m3(k / scale) of what the fp16 engine caches (same inputs: one layer)
+        deq = tab[k8[0, b, :, h0:h0 + n].long()] * ks
+        ref = k16[0, b, :, h0:h0 + n].float()
+        assert ((deq - ref).abs() <= 0.07 * ref.abs() + 1e-2).float().mean().item() > 0.999
+    d8.close()
+    d16.close()
