@@ -70,7 +70,11 @@ def test_paged_decode_is_bit_identical_to_dense(llmie, name, nh, kvh, hs, I, L, 
 @pytest.mark.parametrize("name,nh,kvh,hs,I,L,lens,hist,max_seq,kv8", [
     ("b1_s300", 8, 8, 128, 1024, 2, [300], [0], 384, False), ("ragged_b3_gqa", 16, 4, 128, 1024, 2, [70, 257, 129], [0, 0, 0], 384, False),
     ("history_chunks", 8, 8, 128, 768, 2, [100, 64], [150, 200], 384, False), ("fp8kv_b2", 8, 8, 128, 768, 2, [200, 131], [0, 0], 256, True),
-    ("equal_b2_then_decode", 8, 8, 128, 512, 1, [140, 140], [0, 0], 256, False)])
+    ("equal_b2_then_decode", 8, 8, 128, 512, 1, [140, 140], [0, 0], 256, False),
+    # the cases above run the flash kernel's 64-row form (fewer 128-row query tiles than CUs); these select the other two
+    ("rt2_b8_gqa_history", 16, 4, 128, 512, 1, [256, 130, 200, 256, 129, 20, 255, 140], [10, 7, 5, 64, 9, 3, 100, 12], 384, False),
+    ("rt2_b8_fp8kv", 16, 4, 128, 512, 1, [256, 250, 129, 256, 200, 131, 256, 140], [0] * 8, 256, True),
+    ("w8_long_fp8kv", 16, 16, 128, 512, 1, [1100, 600], [0, 0], 1152, True)])
 def test_paged_prefill_is_bit_identical_to_dense(llmie, name, nh, kvh, hs, I, L, lens, hist, max_seq, kv8):
     """llmie_decoder_prefill_paged == llmie_decoder_prefill (hidden states and every cache row), then one decode step on
     the pages it wrote == the dense decode step."""
